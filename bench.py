@@ -1,0 +1,367 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the RX demodulation hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload c2|c3|c4|c1]
+
+A "step" is one pass of the hot path (gsdr_demod_process_device through the
+C ABI) over one 1 M-sample buffer of synthetic IQ that is already resident in
+HBM (ring of distinct buffers made by the HIP source kernel before the timed
+region).  One independent synthetic 200 Msps stream per GPU, no inter-GPU data
+traffic (front-end streams are independent: SURVEY.md section 8e), so scaling
+is "weak" and `value` is the aggregate Msamples/s of all ranks.
+
+For N > 1 the driver launches this file under torch.distributed.run; the
+process group (RCCL) is used ONLY for the barrier and the max-over-ranks of the
+elapsed time.
+
+Rank 0 prints ONE JSON line (contract in the task statement), with
+  roofline      dominant kernel vs the roof that bounds it (FP32 compute for the
+                fused DDC, HBM for the chirp path); `roofline_hbm` always
+                carries the HBM view (north_star asks for HBM GB/s),
+  cpu_baseline  the CPU oracle (OpenMP, all host cores) on a bounded sample of
+                the same workload, N = 1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+RATE = 200_000_000
+L = 1_000_000
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: FP32 vector == FP32 matrix peak
+
+WORKLOADS = {
+    # BASELINE.json configs[1]
+    "c2": dict(kind="direct", n_tones=256, decim=100, pf_average=4,
+               name="256-tone DDC + polyphase FIR, decim=100, 200 Msps synthetic stream"),
+    # configs[2] / configs[4]
+    "c3": dict(kind="direct", n_tones=2048, decim=1000, pf_average=4,
+               name="2048-tone DDC readout, decim=1000, 200 Msps"),
+    # configs[3]
+    "c4": dict(kind="chirp", decim=1, chirp_t=1.0, swipe_s=1_000_000,
+               name="Chirp VNA demod (USRP_VNA), 1e6-point sweep over 200 MHz, lock-in ppt=200"),
+    # configs[0] shape on the GPU (the CPU-runnable plumbing case)
+    "c1": dict(kind="direct", n_tones=16, decim=100, pf_average=4, rate=100_000_000,
+               name="16-tone DDC, decim=100, 100 Msps"),
+}
+
+
+# --------------------------------------------------------------------------
+# multi-process plumbing (covered by tests/test_multiproc.py with gloo)
+# --------------------------------------------------------------------------
+def dist_env():
+    """(rank, local_rank, world_size) from the torchrun environment."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def stream_seed(rank: int) -> int:
+    """Seed of the synthetic stream owned by `rank`."""
+    return 20251004 + rank
+
+
+def init_group(backend: str):
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend)
+    return dist
+
+
+def barrier(dist, device=None):
+    if dist is None:
+        return
+    import torch
+    t = torch.zeros(1, device=device) if device is not None else torch.zeros(1)
+    dist.all_reduce(t)
+    if device is not None and device.type == "cuda":
+        torch.cuda.synchronize(device)
+
+
+def max_over_ranks(dist, seconds: float, device=None) -> float:
+    if dist is None:
+        return seconds
+    import torch
+    t = torch.tensor([seconds], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(dist, v: float, device=None) -> float:
+    if dist is None:
+        return v
+    import torch
+    t = torch.tensor([v], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+# --------------------------------------------------------------------------
+# workload construction
+# --------------------------------------------------------------------------
+def algorithmic(wl, n_tones):
+    """(bytes, flops) per input sample, SURVEY.md section 8d."""
+    if wl["kind"] == "direct":
+        M, f = wl["decim"], wl["pf_average"]
+        return 8.0 * (1.0 + n_tones / M), float(n_tones * (6 + 4 * f))
+    ppt = 200 * wl["decim"]
+    return 8.0 + 8.0 / ppt, 8.0 + 30.0
+
+
+def build_workload(wl, device, seed, ring=8, n_tones=None):
+    import torch
+    import gpu_sdr_amd as g
+    from gpu_sdr_amd.source import device_chirp, device_tones, tone_comb
+    rate = wl.get("rate", RATE)
+    bufs = [torch.empty(L, dtype=torch.complex64, device=device) for _ in range(ring)]
+    if wl["kind"] == "direct":
+        N = n_tones or wl["n_tones"]
+        freq, ampl, phase = tone_comb(N, rate, seed)
+        p = g.param(mode="RX", rate=rate, buffer_len=L, decim=wl["decim"], pf_average=wl["pf_average"],
+                    freq=[int(f) for f in freq], wave_type=[g.w_type.DIRECT] * N)
+        for i, b in enumerate(bufs):
+            device_tones(b, i * L, rate, freq, ampl, phase, sigma=1e-3, seed=seed * 1000 + i)
+    else:
+        N = 1
+        p = g.param(mode="RX", rate=rate, buffer_len=L, decim=wl["decim"], freq=[-rate // 2],
+                    chirp_f=[rate // 2], swipe_s=[wl["swipe_s"]], chirp_t=[wl["chirp_t"]],
+                    wave_type=[g.w_type.CHIRP])
+        cp = g.chirp_derive(rate, -rate // 2, rate // 2, wl["swipe_s"], wl["chirp_t"])
+        gen = torch.Generator(device=device).manual_seed(seed)
+        for i, b in enumerate(bufs):
+            device_chirp(b, i * L, cp, scale=0.5)
+            b += 1e-3 * torch.view_as_complex(torch.randn(L, 2, device=device, generator=gen))
+    dem = g.RX_buffer_demodulator(p, device_index=device.index)
+    out = torch.empty(dem.out_capacity, dtype=torch.complex64, device=device)
+    torch.cuda.synchronize(device)
+    return dem, bufs, out, N, p
+
+
+def run_steps(dem, bufs, out, steps):
+    n = 0
+    for k in range(steps):
+        n = dem.process(bufs[k % len(bufs)], out)
+    return n
+
+
+def time_workload(wl, device, seed, steps, warmup, dist=None, n_tones=None, profile=True):
+    import torch
+    dem, bufs, out, N, _ = build_workload(wl, device, seed, n_tones=n_tones)
+    run_steps(dem, bufs, out, warmup)
+    torch.cuda.synchronize(device)
+    if profile:
+        dem.profile_enable(True)
+    barrier(dist, device)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    run_steps(dem, bufs, out, steps)
+    torch.cuda.synchronize(device)
+    t1 = time.perf_counter()
+    barrier(dist, device)
+    elapsed = max_over_ranks(dist, t1 - t0, device)
+    kn, kms = dem.profile_read() if profile else (0, 0.0)
+    kname = dem.kernel_name
+    dem.close()
+    return dict(elapsed=elapsed, local_elapsed=t1 - t0, kernel_launches=kn, kernel_ms=kms,
+                kernel=kname, n_tones=N)
+
+
+def max_realtime_tones(device, seed, budget_s=60.0):
+    """Largest N (multiple of 1024) sustaining >= 200 Msps over 200 consecutive
+    1 M-sample buffers with decim=1000, f=4."""
+    wl = dict(WORKLOADS["c3"])
+    t_start = time.perf_counter()
+    best, probes = 0, []
+    lo, hi = 2048, None
+    n = 2048
+    while time.perf_counter() - t_start < budget_s:
+        r = time_workload(wl, device, seed, steps=200, warmup=5, n_tones=n, profile=False)
+        msps = 200 * L / r["elapsed"] / 1e6
+        probes.append((n, round(msps, 1)))
+        if msps >= 200.0:
+            best, lo = n, n
+            n = n * 2 if hi is None else (lo + hi) // 2 // 1024 * 1024
+        else:
+            hi = n
+            n = (lo + hi) // 2 // 1024 * 1024
+        if hi is not None and (hi - lo <= 1024 or n <= lo):
+            break
+        if n > 65536:
+            break
+    return best, probes
+
+
+# --------------------------------------------------------------------------
+# CPU baselines (rank 0, N = 1 only)
+# --------------------------------------------------------------------------
+def cpu_baseline_oracle(wl, seed, min_seconds=8.0, max_buffers=6):
+    """The CPU oracle (kind "port": OpenMP C restatement of the reference
+    algorithm) on a bounded sample of the same workload."""
+    import numpy as np
+    import oracle
+    from gpu_sdr_amd.source import tone_comb
+    oracle.build()
+    rate = wl.get("rate", RATE)
+    rng = np.random.default_rng(seed)
+    if wl["kind"] == "direct":
+        N = wl["n_tones"]
+        freq, _, _ = tone_comb(N, rate, seed)
+        dem = oracle.Direct(freq, rate, wl["decim"], wl["pf_average"], L)
+        what = f"{N} tones"
+    else:
+        dem = oracle.Chirp(rate, -rate // 2, rate // 2, wl["swipe_s"], wl["chirp_t"], wl["decim"], L)
+        what = "chirp lock-in"
+    x = (rng.standard_normal(L) + 1j * rng.standard_normal(L)).astype(np.complex64)
+    t0 = time.perf_counter()
+    nb = 0
+    while nb < max_buffers and (nb == 0 or time.perf_counter() - t0 < min_seconds):
+        dem.process(x)
+        nb += 1
+    dt = time.perf_counter() - t0
+    return dict(value=round(nb * L / dt / 1e6, 4), unit="Msamples/s", cores=oracle.num_threads(),
+                kind="port", sample=f"{nb} x 1M-sample buffers, {what}, oracle/gsdr_oracle.c (OpenMP), {dt:.1f} s")
+
+
+def cpu_baseline_numpy(wl, seed, tones=16):
+    """pyUSRP/numpy offline demod recipe (ref: scripts/raw_data_analisys.py:55-68):
+    per tone conj(exp(2 pi i f n / rate)) * Z then scipy.signal.decimate(ftype='fir')."""
+    import numpy as np
+    from scipy import signal
+    from gpu_sdr_amd.source import tone_comb
+    if wl["kind"] != "direct":
+        return None
+    rate = wl.get("rate", RATE)
+    freq, _, _ = tone_comb(wl["n_tones"], rate, seed)
+    rng = np.random.default_rng(seed)
+    Z = (rng.standard_normal(L) + 1j * rng.standard_normal(L)).astype(np.complex64)
+    n = np.arange(L)
+    t0 = time.perf_counter()
+    for f in freq[:tones]:
+        res = np.conj(np.exp(1.j * (np.pi * 2. * f / rate * n))) * Z
+        signal.decimate(res, wl["decim"], ftype="fir")
+    dt = time.perf_counter() - t0
+    tone_msps = tones * L / dt / 1e6
+    return dict(value=round(tone_msps / wl["n_tones"], 5), unit="Msamples/s", cores=1, kind="port",
+                tone_msamples_per_s=round(tone_msps, 3),
+                sample=f"{tones} of {wl['n_tones']} tones x 1 buffer, numpy/scipy recipe of "
+                       f"scripts/raw_data_analisys.py:55-68, single process, {dt:.1f} s; value scaled to all tones")
+
+
+def recorded_traffic(workload: str):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 --pmc runs
+    committed under profiles/ (FETCH_SIZE corrected x2 per MI355X_MICROARCH.md)."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        return json.load(open(path)).get(workload, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+# --------------------------------------------------------------------------
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-extras", action="store_true", help="skip c3/c4/max-tone extras")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    args = ap.parse_args()
+
+    rank, local_rank, world = dist_env()
+    if args.gpus > 1 and world == 1:
+        # convenience: re-launch under torchrun as a child process (never exec
+        # after the GPU may have been touched)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+               f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", "29517",
+               os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
+    import torch
+    if not torch.cuda.is_available():
+        print("bench.py needs a GPU (the product path has no CPU fallback)", file=sys.stderr)
+        sys.exit(2)
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    dist = init_group("nccl") if world > 1 else None
+
+    wl = WORKLOADS[args.workload]
+    seed = stream_seed(rank)
+    r = time_workload(wl, device, seed, args.steps, args.warmup, dist)
+    samples_total = args.steps * L * world
+    value = samples_total / r["elapsed"] / 1e6
+    ms_per_step = r["elapsed"] / args.steps * 1e3
+
+    ab, af = algorithmic(wl, r["n_tones"])
+    kt = (r["kernel_ms"] / r["kernel_launches"] * 1e-3) if r["kernel_launches"] else None
+    roof_hbm = roof = None
+    if kt:
+        gbs = ab * L / kt / 1e9
+        tfl = af * L / kt / 1e12
+        traffic = recorded_traffic(args.workload)
+        roof_hbm = dict(bound="hbm", achieved=round(gbs, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(gbs / HBM_PEAK_GBS, 5), traffic=traffic,
+                        kernel=r["kernel"], kernel_us=round(kt * 1e6, 2))
+        if wl["kind"] == "direct":
+            # fused DDC: ~1800 flop/B, FP32-compute bound. The FP32
+            # vector peak equals the FP32 (f32-input) MFMA peak on gfx950: 157.3 TF.
+            roof = dict(bound="mfma", pipe="fp32 valu (no MFMA used; same 157.3 TF peak)",
+                        achieved=round(tfl, 3), peak=FP32_PEAK_TFLOPS, unit="TFLOP/s",
+                        frac=round(tfl / FP32_PEAK_TFLOPS, 4), traffic=traffic,
+                        kernel=r["kernel"], kernel_us=round(kt * 1e6, 2))
+        else:
+            roof = roof_hbm
+
+    line = {
+        "metric": "IQ Msamples/s ingested (one synthetic 200 Msps stream per GPU)",
+        "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": wl["name"], "key": args.workload, "buffer_len": L,
+                   "rate": wl.get("rate", RATE), "tones_per_stream": r["n_tones"],
+                   "streams": world, "parallelism": f"{world} independent stream(s), one per GPU, no collective"},
+        "realtime_factor": round(value / world / (wl.get("rate", RATE) / 1e6), 3),
+        "roofline": roof, "roofline_hbm": roof_hbm,
+    }
+
+    if world == 1 and rank == 0:
+        if not args.no_extras:
+            extras = {}
+            for key in ("c3", "c4"):
+                if key == args.workload:
+                    continue
+                e = time_workload(WORKLOADS[key], device, seed, steps=100, warmup=5)
+                eb, ef = algorithmic(WORKLOADS[key], e["n_tones"])
+                ekt = e["kernel_ms"] / max(e["kernel_launches"], 1) * 1e-3
+                extras[key] = dict(msamples_per_s=round(100 * L / e["elapsed"] / 1e6, 2),
+                                   kernel=e["kernel"], kernel_us=round(ekt * 1e6, 2),
+                                   hbm_gbs=round(eb * L / ekt / 1e9, 2),
+                                   fp32_tflops=round(ef * L / ekt / 1e12, 3))
+            best, probes = max_realtime_tones(device, seed)
+            extras["max_realtime_tones_200Msps"] = dict(value=best, decim=1000, pf_average=4,
+                                                        buffers=200, probes=probes)
+            line["extras"] = extras
+        if not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline_oracle(wl, seed)
+            nb = cpu_baseline_numpy(wl, seed)
+            if nb:
+                line["cpu_baseline_numpy"] = nb
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

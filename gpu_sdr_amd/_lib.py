@@ -1,0 +1,118 @@
+"""ctypes binding of libgsdr.so (include/gsdr.h).
+
+The product path has NO CPU fallback: if the HIP library is missing this module
+raises at import of the symbols, and every compute call needs a GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgsdr.so")
+
+
+class GsdrLibraryError(RuntimeError):
+    pass
+
+
+class ParamC(C.Structure):
+    """struct gsdr_param_c (include/gsdr.h)"""
+    _fields_ = [
+        ("rate", C.c_int),
+        ("decim", C.c_longlong),
+        ("fft_tones", C.c_int),
+        ("pf_average", C.c_longlong),
+        ("buffer_len", C.c_longlong),
+        ("wave_type", C.POINTER(C.c_int)),
+        ("n_wave_type", C.c_int),
+        ("freq", C.POINTER(C.c_int)),
+        ("n_freq", C.c_int),
+        ("chirp_t", C.POINTER(C.c_float)),
+        ("n_chirp_t", C.c_int),
+        ("chirp_f", C.POINTER(C.c_int)),
+        ("n_chirp_f", C.c_int),
+        ("swipe_s", C.POINTER(C.c_int)),
+        ("n_swipe_s", C.c_int),
+        ("device_index", C.c_int),
+    ]
+
+
+class BufferHelperC(C.Structure):
+    """struct gsdr_buffer_helper"""
+    _fields_ = [(n, C.c_int) for n in (
+        "n_tones", "eff_length", "buffer_len", "average", "n_eff_tones",
+        "new_0", "copy_size", "current_batch", "spare_samples", "spare_begin")]
+
+
+class VnaHelperC(C.Structure):
+    """struct gsdr_vna_helper"""
+    _fields_ = [(n, C.c_int) for n in (
+        "valid_size", "new0", "total_len", "spare_begin", "ppt", "buffer_len")]
+
+
+class ChirpParamC(C.Structure):
+    """struct gsdr_chirp_param"""
+    _fields_ = [("num_steps", C.c_ulonglong), ("length", C.c_ulonglong),
+                ("chirpness", C.c_uint), ("f0", C.c_int)]
+
+
+# every symbol include/gsdr.h declares: (name, restype, argtypes)
+_vp, _ip, _fp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float)
+SIGNATURES = [
+    ("gsdr_demod_create", _vp, [C.POINTER(ParamC)]),
+    ("gsdr_demod_process", C.c_int, [_vp, _vp, _vp]),
+    ("gsdr_demod_process_device", C.c_int, [_vp, _vp, _vp, _vp]),
+    ("gsdr_demod_close", None, [_vp]),
+    ("gsdr_last_error", C.c_char_p, [_vp]),
+    ("gsdr_abi_version", C.c_int, []),
+    ("gsdr_demod_mode", C.c_int, [_vp]),
+    ("gsdr_demod_channels", C.c_int, [_vp]),
+    ("gsdr_demod_out_capacity", C.c_longlong, [_vp]),
+    ("gsdr_demod_fcut", C.c_float, [_vp]),
+    ("gsdr_demod_get_window", C.c_int, [_vp, _fp, C.c_int]),
+    ("gsdr_demod_get_bins", C.c_int, [_vp, _ip, C.c_int]),
+    ("gsdr_demod_profile_enable", None, [_vp, C.c_int]),
+    ("gsdr_demod_profile_read", C.c_int, [_vp, C.POINTER(C.c_double)]),
+    ("gsdr_demod_kernel_name", C.c_char_p, [_vp]),
+    ("gsdr_make_sinc_window", None, [C.c_int, C.c_float, _fp]),
+    ("gsdr_make_flat_window", None, [C.c_int, C.c_int, _fp]),
+    ("gsdr_buffer_helper_init", None, [C.POINTER(BufferHelperC)] + [C.c_int] * 4),
+    ("gsdr_buffer_helper_update", None, [C.POINTER(BufferHelperC)]),
+    ("gsdr_vna_helper_init", None, [C.POINTER(VnaHelperC), C.c_int, C.c_int]),
+    ("gsdr_vna_helper_update", None, [C.POINTER(VnaHelperC)]),
+    ("gsdr_pfb_tone_bins", None, [C.c_int, C.c_int, _ip, C.c_int, _ip]),
+    ("gsdr_pfb_batching", C.c_int, [C.c_longlong, C.c_int, C.c_longlong]),
+    ("gsdr_chirp_derive", None, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                 C.POINTER(ChirpParamC)]),
+    ("gsdr_source_tones", C.c_int, [_vp, C.c_longlong, C.c_longlong, C.c_int, _ip, _fp, _fp,
+                                    C.c_int, C.c_float, C.c_ulonglong, _vp]),
+    ("gsdr_source_chirp", C.c_int, [_vp, C.c_longlong, C.c_ulonglong,
+                                    C.POINTER(ChirpParamC), C.c_float, _vp]),
+]
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libgsdr.so (built in-tree by gpu_sdr_amd/csrc/Makefile). Fails loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GsdrLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` or `make -C gpu_sdr_amd/csrc`. There is no CPU fallback.")
+    try:
+        L = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise GsdrLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, restype, argtypes in SIGNATURES:
+        try:
+            fn = getattr(L, name)
+        except AttributeError as e:
+            raise GsdrLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = L
+    return L

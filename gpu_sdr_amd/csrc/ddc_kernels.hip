@@ -1,0 +1,322 @@
+// ddc_kernels.hip -- fused per-tone digital down-converter for gfx950.
+//
+// One kernel serves both DIRECT (ref: direct_demodulator_integer
+// cpp/kernels.cu:45-86 + FIR cpp/fir.cu:44-88 + cublasCgeam transpose
+// cpp/USRP_demodulator.cpp:422-433) and TONES (ref: polyphase_filter
+// cpp/kernels.cu:474-516 + cufftExecC2C cpp/USRP_demodulator.cpp:501 +
+// tone_select cpp/kernels.cu:531-554), because both compute
+//
+//     y[n, G] = sum_{t < M*F} h[t] * x[(G-F+1)*M + t] * w_n^{s(t)}
+//
+// with w_n = exp(-2*pi*i*f_n/rate) (DIRECT: f_n in Hz, rate = sample rate;
+// TONES: f_n = FFT bin, rate = nfft, M = nfft, F = pf_average), i.e. the
+// reference's N*L intermediate, its N*(F+4) cuBLAS launches per buffer and its
+// full-width FFT never exist here.
+//
+// Mapping (MI355X, wave64):
+//   * one LANE per tone, one WAVE per (64 tones x chunk of consecutive input
+//     blocks).  The IQ samples and the FIR taps are wave-uniform, so they are
+//     fetched through the scalar data path (s_load -> SGPR) and enter the VALU
+//     as scalar operands: no LDS traffic, no per-lane loads in the inner loop
+//     (an LDS broadcast of the same bytes would cost 4x the LDS bandwidth the
+//     CU has).
+//   * NCO without per-sample sincos: the phasor of sample s = s0 + K*q + lo is
+//     P_q * B[lo] where B[lo] = w_n^lo (lo < K) sits in VGPRs for the whole
+//     kernel and P_q is advanced once per K samples in double precision from
+//     an exact integer phase at the chunk start.  The inner loop is then
+//     4 (mix) + 2F (real-tap MAC) FMA-class ops per tone-sample and the P_q
+//     rotation is amortised over K samples.
+//   * chunk boundaries: a chunk's first F-1 outputs miss the blocks of the
+//     previous chunk; each chunk therefore writes its partial head sums to
+//     `out`, its F-1 partial tail sums to `tails`, and ddc_fixup adds the two.
+//     The tail of the last chunk is the stream carry for the next call (the
+//     reference's FIR::_dout carry, cpp/fir.cu:64-69).
+#include <hip/hip_runtime.h>
+
+#include "ddc_kernels.h"
+
+namespace gsdr {
+
+// exp(-2*pi*i * ph/rate) for an exact integer phase 0 <= ph < rate.
+__device__ __forceinline__ void exact_phasor(unsigned long long ph, unsigned rate,
+                                             double &re, double &im) {
+    double s, c;
+    sincospi(2.0 * ((double)ph / (double)rate), &s, &c);
+    re = c;
+    im = -s;
+}
+
+template <int F, int K>
+__global__ __launch_bounds__(256) void ddc_kernel(
+    const float2 *__restrict__ x,       // input samples, block b starts at x[b*M]
+    const float *__restrict__ taps_t,   // [M][F]: taps_t[m*F+j] = h[j*M+m]
+    const float2 *__restrict__ btab,    // [K][Npad]: w_n^lo
+    const double2 *__restrict__ wk,     // [Npad]: w_n^K
+    const double2 *__restrict__ wrem,   // [Npad]: w_n^(M mod K)
+    const unsigned *__restrict__ fmod,  // [Npad]: f_n mod rate
+    float2 *__restrict__ out,           // [rows][N] sample-major
+    float2 *__restrict__ tails,         // [nch][F-1][Npad], slot c = tail of chunk c-1
+    float2 *__restrict__ carry_out,     // [F-1][Npad] tail of the last chunk, or null
+    DdcShape sh) {
+    const int lane = threadIdx.x & 63;
+    // wave-uniform ids must be SGPRs so that x/taps become scalar loads
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wave = (int)blockIdx.x * 4 + wid;
+    if (wave >= sh.TW * sh.nch) return;
+    const int tw = wave % sh.TW;
+    const int chunk = wave / sh.TW;
+    const int n = tw * 64 + lane;
+    const int M = sh.M, N = sh.N, Npad = sh.Npad;
+
+    float2 B[K];
+#pragma unroll
+    for (int lo = 0; lo < K; ++lo) B[lo] = btab[(size_t)lo * Npad + n];
+    const double2 WK = wk[n];
+    const double2 WR = wrem[n];
+
+    const int b0 = (int)(((long long)chunk * sh.nblk) / sh.nch);
+    const int b1 = (int)(((long long)(chunk + 1) * sh.nblk) / sh.nch);
+
+    // exact NCO phase at the first sample of the chunk
+    // ref: kernels.cu:66-69  ii=(j+idx)%rate; phase=(tf*ii)%rate
+    const unsigned long long s0 = (sh.idx0 + (unsigned long long)b0 * (unsigned)M) % sh.rate;
+    const unsigned long long ph = ((unsigned long long)fmod[n] * s0) % sh.rate;
+    double Pr, Pi;
+    exact_phasor(ph, sh.rate, Pr, Pi);
+
+    float2 A[F];  // A[k]: partial sum of output G = b + k while block b is processed
+#pragma unroll
+    for (int k = 0; k < F; ++k) A[k] = make_float2(0.f, 0.f);
+
+    const int nfull = M / K;
+    const int R = M - nfull * K;
+
+    for (int b = b0; b < b1; ++b) {
+        const float2 *__restrict__ xb = x + (size_t)b * M;
+        int m = 0;
+        for (int q = 0; q < nfull; ++q, m += K) {
+            float2 S[F];
+#pragma unroll
+            for (int j = 0; j < F; ++j) S[j] = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int lo = 0; lo < K; ++lo) {
+                const float2 xs = xb[m + lo];  // wave-uniform -> SGPR pair
+                const float ur = xs.x * B[lo].x - xs.y * B[lo].y;
+                const float ui = xs.x * B[lo].y + xs.y * B[lo].x;
+#pragma unroll
+                for (int j = 0; j < F; ++j) {
+                    const float h = taps_t[(size_t)(m + lo) * F + j];  // wave-uniform
+                    S[j].x = fmaf(h, ur, S[j].x);
+                    S[j].y = fmaf(h, ui, S[j].y);
+                }
+            }
+            const float pr = (float)Pr, pi = (float)Pi;
+#pragma unroll
+            for (int j = 0; j < F; ++j) {
+                // tap phase j of block b feeds output G = b + F-1-j  (fir.cu:56-61)
+                A[F - 1 - j].x += pr * S[j].x - pi * S[j].y;
+                A[F - 1 - j].y += pr * S[j].y + pi * S[j].x;
+            }
+            const double t = Pr * WK.x - Pi * WK.y;
+            Pi = Pr * WK.y + Pi * WK.x;
+            Pr = t;
+        }
+        if (R) {
+            float2 S[F];
+#pragma unroll
+            for (int j = 0; j < F; ++j) S[j] = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int lo = 0; lo < K; ++lo) {
+                if (lo < R) {
+                    const float2 xs = xb[m + lo];
+                    const float ur = xs.x * B[lo].x - xs.y * B[lo].y;
+                    const float ui = xs.x * B[lo].y + xs.y * B[lo].x;
+#pragma unroll
+                    for (int j = 0; j < F; ++j) {
+                        const float h = taps_t[(size_t)(m + lo) * F + j];
+                        S[j].x = fmaf(h, ur, S[j].x);
+                        S[j].y = fmaf(h, ui, S[j].y);
+                    }
+                }
+            }
+            const float pr = (float)Pr, pi = (float)Pi;
+#pragma unroll
+            for (int j = 0; j < F; ++j) {
+                A[F - 1 - j].x += pr * S[j].x - pi * S[j].y;
+                A[F - 1 - j].y += pr * S[j].y + pi * S[j].x;
+            }
+            const double t = Pr * WR.x - Pi * WR.y;
+            Pi = Pr * WR.y + Pi * WR.x;
+            Pr = t;
+        }
+        // output G = b has now seen every block this chunk can give it
+        if (b >= sh.g_off && n < N) out[(size_t)(b - sh.g_off) * N + n] = A[0];
+#pragma unroll
+        for (int k = 0; k + 1 < F; ++k) A[k] = A[k + 1];
+        A[F - 1] = make_float2(0.f, 0.f);
+    }
+
+    if (F > 1) {
+        float2 *dst = (chunk == sh.nch - 1) ? carry_out
+                                            : tails + (size_t)(chunk + 1) * (F - 1) * Npad;
+        if (dst) {
+#pragma unroll
+            for (int k = 0; k + 1 < F; ++k) dst[(size_t)k * Npad + n] = A[k];
+        }
+    }
+}
+
+// Adds the tail partial sums of chunk c-1 (or the stream carry, c == 0) to the
+// head outputs of chunk c.  Tiny: nch*(F-1)*Npad threads.
+__global__ void ddc_fixup(float2 *__restrict__ out, const float2 *__restrict__ tails,
+                          const float2 *__restrict__ carry_in, float2 *__restrict__ carry_out,
+                          int F, DdcShape sh) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int Fm1 = F - 1;
+    const long long total = (long long)sh.nch * Fm1 * sh.Npad;
+    if (t >= total) return;
+    const int n = (int)(t % sh.Npad);
+    const int k = (int)((t / sh.Npad) % Fm1);
+    const int c = (int)(t / ((long long)sh.Npad * Fm1));
+    float2 src;
+    if (c == 0) {
+        if (!carry_in) return;
+        src = carry_in[(size_t)k * sh.Npad + n];
+    } else {
+        src = tails[((size_t)c * Fm1 + k) * sh.Npad + n];
+    }
+    const int b0 = (int)(((long long)c * sh.nblk) / sh.nch);
+    const int b1 = (int)(((long long)(c + 1) * sh.nblk) / sh.nch);
+    const int G = b0 + k;
+    if (G < b1) {
+        if (G >= sh.g_off && n < sh.N) {
+            float2 *o = out + (size_t)(G - sh.g_off) * sh.N + n;
+            o->x += src.x;
+            o->y += src.y;
+        }
+    } else if (carry_out) {
+        // only reachable with a single chunk shorter than F-1 blocks (the host
+        // guarantees nch == 1 then): the old carry outlives this buffer.
+        float2 *o = carry_out + (size_t)(G - b1) * sh.Npad + n;
+        o->x += src.x;
+        o->y += src.y;
+    }
+}
+
+// DIRECT with decim == 0: out[j][n] = x[j] * w_n^{idx+j}
+// ref: direct_demodulator_integer (kernels.cu:45-86) + cublasCgeam transpose
+// (USRP_demodulator.cpp:444-455).  HBM-write bound (8 B per tone-sample).
+template <int K>
+__global__ __launch_bounds__(256) void mix_kernel(
+    const float2 *__restrict__ x, const float2 *__restrict__ btab,
+    const double2 *__restrict__ wk, const unsigned *__restrict__ fmod,
+    float2 *__restrict__ out, DdcShape sh) {
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wave = (int)blockIdx.x * 4 + wid;
+    if (wave >= sh.TW * sh.nch) return;
+    const int tw = wave % sh.TW;
+    const int chunk = wave / sh.TW;
+    const int n = tw * 64 + lane;
+    const int N = sh.N, Npad = sh.Npad;
+
+    float2 B[K];
+#pragma unroll
+    for (int lo = 0; lo < K; ++lo) B[lo] = btab[(size_t)lo * Npad + n];
+    const double2 WK = wk[n];
+
+    // chunks are whole multiples of K samples (sh.M = samples per unit = K)
+    const long long u0 = ((long long)chunk * sh.nblk) / sh.nch;
+    const long long u1 = ((long long)(chunk + 1) * sh.nblk) / sh.nch;
+    const long long total = sh.total;  // L
+    const unsigned long long s0 = (sh.idx0 + (unsigned long long)u0 * K) % sh.rate;
+    const unsigned long long ph = ((unsigned long long)fmod[n] * s0) % sh.rate;
+    double Pr, Pi;
+    exact_phasor(ph, sh.rate, Pr, Pi);
+
+    for (long long u = u0; u < u1; ++u) {
+        const long long base = u * K;
+        const float pr = (float)Pr, pi = (float)Pi;
+#pragma unroll
+        for (int lo = 0; lo < K; ++lo) {
+            if (base + lo < total) {
+                const float2 xs = x[base + lo];
+                const float ur = xs.x * B[lo].x - xs.y * B[lo].y;
+                const float ui = xs.x * B[lo].y + xs.y * B[lo].x;
+                float2 o;
+                o.x = pr * ur - pi * ui;
+                o.y = pr * ui + pi * ur;
+                if (n < N) out[(size_t)(base + lo) * N + n] = o;
+            }
+        }
+        const double t = Pr * WK.x - Pi * WK.y;
+        Pi = Pr * WK.y + Pi * WK.x;
+        Pr = t;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+template <int F, int K>
+static hipError_t launch_ddc_fk(const DdcLaunch &a, hipStream_t st) {
+    const int waves = a.sh.TW * a.sh.nch;
+    const int grid = (waves + 3) / 4;
+    hipLaunchKernelGGL((ddc_kernel<F, K>), dim3(grid), dim3(256), 0, st, a.x, a.taps_t, a.btab,
+                       a.wk, a.wrem, a.fmod, a.out, a.tails, a.carry_out, a.sh);
+    return hipGetLastError();
+}
+
+template <int K>
+static hipError_t launch_ddc_k(int F, const DdcLaunch &a, hipStream_t st) {
+    switch (F) {
+        case 1: return launch_ddc_fk<1, K>(a, st);
+        case 2: return launch_ddc_fk<2, K>(a, st);
+        case 3: return launch_ddc_fk<3, K>(a, st);
+        case 4: return launch_ddc_fk<4, K>(a, st);
+        case 5: return launch_ddc_fk<5, K>(a, st);
+        case 6: return launch_ddc_fk<6, K>(a, st);
+        case 7: return launch_ddc_fk<7, K>(a, st);
+        case 8: return launch_ddc_fk<8, K>(a, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_ddc(int F, int K, const DdcLaunch &a, hipStream_t st, hipEvent_t stop) {
+    hipError_t e;
+    if (K == 16) e = launch_ddc_k<16>(F, a, st);
+    else if (K == 32) e = launch_ddc_k<32>(F, a, st);
+    else return hipErrorInvalidValue;
+    if (e != hipSuccess) return e;
+    if (stop) {
+        e = hipEventRecord(stop, st);
+        if (e != hipSuccess) return e;
+    }
+    if (F > 1) {
+        const long long total = (long long)a.sh.nch * (F - 1) * a.sh.Npad;
+        const int grid = (int)((total + 255) / 256);
+        hipLaunchKernelGGL(ddc_fixup, dim3(grid), dim3(256), 0, st, a.out, a.tails, a.carry_in,
+                           a.carry_out, F, a.sh);
+        e = hipGetLastError();
+    }
+    return e;
+}
+
+hipError_t launch_mix(int K, const DdcLaunch &a, hipStream_t st) {
+    const int waves = a.sh.TW * a.sh.nch;
+    const int grid = (waves + 3) / 4;
+    if (K == 16)
+        hipLaunchKernelGGL((mix_kernel<16>), dim3(grid), dim3(256), 0, st, a.x, a.btab, a.wk,
+                           a.fmod, a.out, a.sh);
+    else if (K == 32)
+        hipLaunchKernelGGL((mix_kernel<32>), dim3(grid), dim3(256), 0, st, a.x, a.btab, a.wk,
+                           a.fmod, a.out, a.sh);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+const char *ddc_kernel_name() { return "ddc_kernel"; }
+const char *mix_kernel_name() { return "mix_kernel"; }
+
+}  // namespace gsdr

@@ -1,0 +1,728 @@
+// demod.cpp -- C ABI of libgsdr.so (include/gsdr.h): handle lifecycle, mode
+// dispatch, per-buffer sequencing and carry state of the RX demodulator.
+//
+// Host-side counterpart of RX_buffer_demodulator
+// (ref: cpp/USRP_demodulator.cpp, headers/USRP_demodulator.hpp).  All device
+// work is enqueued on one stream per demodulator, like the reference's
+// internal_stream (ref: USRP_demodulator.cpp:44), but nothing here blocks
+// except the host-pointer entry gsdr_demod_process().
+//
+// "ref:" citations are relative to /root/reference.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/gsdr.h"
+#include "ddc_kernels.h"
+
+using gsdr::ChirpShape;
+using gsdr::DdcLaunch;
+using gsdr::DdcShape;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+constexpr int kMaxF = 8;           // tap phases the DDC kernel is instantiated for
+constexpr int kMaxEvents = 8192;   // profiling ring
+
+inline int env_int(const char *name, int dflt) {
+    const char *v = std::getenv(name);
+    return (v && *v) ? std::atoi(v) : dflt;
+}
+
+}  // namespace
+
+struct gsdr_demod {
+    int mode = GSDR_NODSP;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    int N = 0;              // channels = wave_type.size()
+    long long L = 0;        // buffer_len
+    long long decim = 0;
+    long long capacity = 0; // max samples process() can return
+    float fcut = 0.f;
+
+    // host-pointer entry staging
+    float2 *d_in = nullptr, *d_out = nullptr;
+
+    // ---- DDC (DIRECT / TONES) ----
+    int F = 0, K = 16, M = 0, Npad = 0, TW = 0, R = 0;
+    unsigned nco_rate = 1;
+    unsigned long long idx = 0;        // DIRECT_current_index (ref :88, :437-440)
+    int target_waves = 4096;
+    int nch_max = 1;
+    std::vector<float> window;         // taps (DIRECT) / PFB window / VNA profile, real part
+    float *d_taps_t = nullptr;
+    float2 *d_btab = nullptr;
+    double2 *d_wk = nullptr, *d_wrem = nullptr;
+    unsigned *d_fmod = nullptr;
+    float2 *d_tails = nullptr;
+    float2 *d_carry[2] = {nullptr, nullptr};
+    int parity = 0;
+    // ---- TONES ----
+    std::vector<int> bins;
+    int nfft = 0, batching = 0;
+    gsdr_buffer_helper bh{};
+    float2 *d_raw = nullptr;           // raw_input (ref :143)
+    // ---- CHIRP ----
+    ChirpShape cs{};
+    int ppt = 0;
+    gsdr_vna_helper vh{};
+    float *d_profile = nullptr;
+    float2 *d_ccarry[2] = {nullptr, nullptr};
+    int cparity = 0;
+    int carry_len = 0;                 // spare_size (ref :54,:369)
+    unsigned long long last_index = 0; // ref :217,:355
+
+    // ---- profiling ----
+    bool prof = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+    const char *kernel_name = "none";
+};
+
+namespace {
+
+#define HIPCHK(h, expr)                                                                   \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            (h)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                 \
+            return -1;                                                                    \
+        }                                                                                 \
+    } while (0)
+
+int fail_create(gsdr_demod *h, const std::string &msg) {
+    g_create_error = msg;
+    if (h) gsdr_demod_close(h);
+    return -1;
+}
+
+template <typename T>
+hipError_t dev_alloc(T **p, size_t count) {
+    *p = nullptr;
+    if (count == 0) count = 1;
+    return hipMalloc(reinterpret_cast<void **>(p), count * sizeof(T));
+}
+
+template <typename T>
+hipError_t upload(T **dst, const std::vector<T> &src) {
+    hipError_t e = dev_alloc(dst, src.size());
+    if (e != hipSuccess) return e;
+    if (src.empty()) return hipSuccess;
+    return hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice);
+}
+
+// exp(-2*pi*i * ph/rate) for an exact integer phase, in double.
+inline void phasor(unsigned long long ph, unsigned rate, double &re, double &im) {
+    const double a = 2.0 * M_PI * ((double)ph / (double)rate);
+    re = std::cos(a);
+    im = -std::sin(a);
+}
+
+// Builds the per-tone NCO tables of the DDC kernel (see ddc_kernels.hip):
+//   fmod[n] = f_n mod rate, btab[lo][n] = w_n^lo, wk[n] = w_n^K, wrem[n] = w_n^R.
+int build_nco_tables(gsdr_demod *h, const std::vector<long long> &tone, unsigned rate) {
+    const int Npad = h->Npad, K = h->K;
+    std::vector<unsigned> fmod(Npad, 0u);
+    std::vector<float2> btab((size_t)K * Npad);
+    std::vector<double2> wk(Npad), wrem(Npad);
+    for (int n = 0; n < Npad; ++n) {
+        unsigned long long fm = 0;
+        if (n < h->N) {
+            long long r = tone[n] % (long long)rate;
+            if (r < 0) r += rate;
+            fm = (unsigned long long)r;
+        }
+        fmod[n] = (unsigned)fm;
+        for (int lo = 0; lo < K; ++lo) {
+            double re, im;
+            phasor((fm * (unsigned long long)lo) % rate, rate, re, im);
+            btab[(size_t)lo * Npad + n] = make_float2((float)re, (float)im);
+        }
+        double re, im;
+        phasor((fm * (unsigned long long)K) % rate, rate, re, im);
+        wk[n] = make_double2(re, im);
+        phasor((fm * (unsigned long long)h->R) % rate, rate, re, im);
+        wrem[n] = make_double2(re, im);
+    }
+    HIPCHK(h, upload(&h->d_fmod, fmod));
+    HIPCHK(h, upload(&h->d_btab, btab));
+    HIPCHK(h, upload(&h->d_wk, wk));
+    HIPCHK(h, upload(&h->d_wrem, wrem));
+    return 0;
+}
+
+// taps_t[m*F + j] = h[j*M + m]: the F tap phases of input sample m, contiguous.
+int upload_taps_transposed(gsdr_demod *h) {
+    std::vector<float> t((size_t)h->M * h->F);
+    for (int j = 0; j < h->F; ++j)
+        for (int m = 0; m < h->M; ++m) t[(size_t)m * h->F + j] = h->window[(size_t)j * h->M + m];
+    HIPCHK(h, upload(&h->d_taps_t, t));
+    return 0;
+}
+
+int pick_chunks(const gsdr_demod *h, int nblk) {
+    if (nblk <= 0) return 1;
+    long long nch = h->target_waves / (h->TW > 0 ? h->TW : 1);
+    if (nch < 1) nch = 1;
+    const long long cap = (h->F > 1) ? nblk / (h->F - 1) : nblk;  // every chunk >= F-1 blocks
+    if (nch > cap) nch = cap;
+    if (nch < 1) nch = 1;
+    return (int)nch;
+}
+
+int setup_ddc_common(gsdr_demod *h, int F, int M, unsigned rate,
+                     const std::vector<long long> &tone, int max_nblk) {
+    h->F = F;
+    h->M = M;
+    h->nco_rate = rate;
+    h->Npad = ((h->N + 63) / 64) * 64;
+    h->TW = h->Npad / 64;
+    h->K = env_int("GSDR_DDC_K", 16) == 32 ? 32 : 16;
+    h->R = M % h->K;
+    int cus = 256;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess)
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int wps = env_int("GSDR_DDC_WAVES_PER_SIMD", 4);
+    h->target_waves = cus * 4 * (wps > 0 ? wps : 4);
+    h->nch_max = pick_chunks(h, max_nblk);
+    if (build_nco_tables(h, tone, rate)) return -1;
+    if (upload_taps_transposed(h)) return -1;
+    const size_t tail_elems = (size_t)(h->nch_max + 1) * (size_t)(F > 1 ? F - 1 : 1) * h->Npad;
+    HIPCHK(h, dev_alloc(&h->d_tails, tail_elems));
+    HIPCHK(h, hipMemset(h->d_tails, 0, tail_elems * sizeof(float2)));
+    return 0;
+}
+
+int record_begin(gsdr_demod *h, hipStream_t st, hipEvent_t *stop) {
+    *stop = nullptr;
+    if (!h->prof || h->ev_used >= (size_t)kMaxEvents) return 0;
+    if (h->ev_used == h->ev_pool.size()) {
+        hipEvent_t a, b;
+        HIPCHK(h, hipEventCreate(&a));
+        HIPCHK(h, hipEventCreate(&b));
+        h->ev_pool.emplace_back(a, b);
+    }
+    HIPCHK(h, hipEventRecord(h->ev_pool[h->ev_used].first, st));
+    *stop = h->ev_pool[h->ev_used].second;
+    h->ev_used++;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// per-mode enqueue
+// ---------------------------------------------------------------------------
+
+// ref: process_direct, cpp/USRP_demodulator.cpp:400-464
+int enqueue_direct(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t st) {
+    DdcLaunch a{};
+    a.x = in;
+    a.taps_t = h->d_taps_t;
+    a.btab = h->d_btab;
+    a.wk = h->d_wk;
+    a.wrem = h->d_wrem;
+    a.fmod = h->d_fmod;
+    a.out = out;
+    a.sh.N = h->N;
+    a.sh.Npad = h->Npad;
+    a.sh.TW = h->TW;
+    a.sh.rate = h->nco_rate;
+    a.sh.idx0 = h->idx;
+    a.sh.g_off = 0;
+    long long ret;
+    hipEvent_t stop = nullptr;
+    if (h->decim > 0) {
+        a.tails = h->d_tails;
+        a.carry_in = h->d_carry[h->parity];
+        a.carry_out = h->d_carry[h->parity ^ 1];
+        a.sh.M = h->M;
+        a.sh.nblk = (int)(h->L / h->M);
+        a.sh.nch = h->nch_max;
+        if (record_begin(h, st, &stop)) return -1;
+        HIPCHK(h, gsdr::launch_ddc(h->F, h->K, a, st, stop));
+        h->parity ^= 1;
+        ret = (long long)h->N * (h->L / h->M);               // :459
+    } else {
+        a.sh.M = h->K;
+        a.sh.total = h->L;
+        a.sh.nblk = (int)((h->L + h->K - 1) / h->K);
+        long long nch = h->target_waves / h->TW;
+        if (nch < 1) nch = 1;
+        if (nch > a.sh.nblk) nch = a.sh.nblk;
+        a.sh.nch = (int)nch;
+        if (record_begin(h, st, &stop)) return -1;
+        HIPCHK(h, gsdr::launch_mix(h->K, a, st));
+        if (stop) HIPCHK(h, hipEventRecord(stop, st));
+        ret = (long long)h->N * h->L;                        // :457
+    }
+    h->idx = (h->idx + (unsigned long long)h->L) % h->nco_rate;  // :437-440
+    return (int)ret;
+}
+
+// ref: process_pfb (decim == 0 branch), cpp/USRP_demodulator.cpp:486-565
+int enqueue_pfb(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t st) {
+    // :491-495  new buffer goes after the carried samples
+    HIPCHK(h, hipMemcpyAsync(h->d_raw + h->bh.new_0, in, (size_t)h->L * sizeof(float2),
+                             hipMemcpyDeviceToDevice, st));
+    const int cb = h->bh.current_batch;
+    if (cb > 0) {
+        DdcLaunch a{};
+        a.x = h->d_raw;
+        a.taps_t = h->d_taps_t;
+        a.btab = h->d_btab;
+        a.wk = h->d_wk;
+        a.wrem = h->d_wrem;
+        a.fmod = h->d_fmod;
+        a.out = out;
+        a.tails = h->d_tails;
+        a.carry_in = nullptr;   // frames never reach back before raw_input[0]
+        a.carry_out = nullptr;
+        a.sh.N = h->N;
+        a.sh.Npad = h->Npad;
+        a.sh.TW = h->TW;
+        a.sh.rate = h->nco_rate;
+        a.sh.idx0 = 0;          // raw_input[0] is always on the frame grid
+        a.sh.M = h->M;
+        a.sh.nblk = cb + h->F - 1;  // frame r spans blocks r .. r+F-1
+        a.sh.g_off = h->F - 1;      // DDC output G <-> frame r = G-(F-1)
+        int nch = pick_chunks(h, a.sh.nblk);
+        if (nch > h->nch_max) nch = h->nch_max;
+        a.sh.nch = nch;
+        hipEvent_t stop = nullptr;
+        if (record_begin(h, st, &stop)) return -1;
+        HIPCHK(h, gsdr::launch_ddc(h->F, h->K, a, st, stop));
+    }
+    // :504-509 carry the unconsumed samples to the front (ranges may overlap,
+    // so go through the spare half of the raw buffer)
+    if (h->bh.spare_samples > 0 && h->bh.spare_begin > 0) {
+        float2 *tmp = h->d_raw + (size_t)h->nfft * h->batching;
+        HIPCHK(h, hipMemcpyAsync(tmp, h->d_raw + h->bh.spare_begin,
+                                 (size_t)h->bh.spare_samples * sizeof(float2),
+                                 hipMemcpyDeviceToDevice, st));
+        HIPCHK(h, hipMemcpyAsync(h->d_raw, tmp, (size_t)h->bh.spare_samples * sizeof(float2),
+                                 hipMemcpyDeviceToDevice, st));
+    }
+    const int ret = h->N * cb;           // :546
+    gsdr_buffer_helper_update(&h->bh);   // :552
+    return ret;
+}
+
+// ref: process_chirp, cpp/USRP_demodulator.cpp:342-397
+int enqueue_chirp(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t st) {
+    hipEvent_t stop = nullptr;
+    int ret;
+    if (h->decim <= 0) {
+        if (record_begin(h, st, &stop)) return -1;
+        HIPCHK(h, gsdr::launch_chirp_demod(in, out, h->L, h->last_index, h->cs, st));
+        if (stop) HIPCHK(h, hipEventRecord(stop, st));
+        ret = (int)h->L;                 // :390
+    } else {
+        const int valid = h->vh.valid_size;      // :361
+        // chirp index of the first carried sample
+        const unsigned long long idx0 =
+            (h->last_index + h->cs.period - (unsigned long long)h->carry_len % h->cs.period) %
+            h->cs.period;
+        if (record_begin(h, st, &stop)) return -1;
+        HIPCHK(h, gsdr::launch_chirp_lockin(h->d_ccarry[h->cparity], h->carry_len, in,
+                                            h->d_profile, h->ppt, valid, out, idx0, h->cs, st));
+        if (stop) HIPCHK(h, hipEventRecord(stop, st));
+        // :369-380 the reference keeps the last new0 DEMODULATED samples; we
+        // keep the same raw samples and re-demodulate them next call.
+        const int new0 = h->vh.new0;
+        if (new0 > 0) {
+            // they are the tail of the logical stage [carry | in]
+            const long long from_in = (long long)new0 <= h->L ? new0 : h->L;
+            const long long from_carry = new0 - from_in;
+            float2 *dst = h->d_ccarry[h->cparity ^ 1];
+            if (from_carry > 0)
+                HIPCHK(h, hipMemcpyAsync(dst, h->d_ccarry[h->cparity] + (h->carry_len - from_carry),
+                                         (size_t)from_carry * sizeof(float2),
+                                         hipMemcpyDeviceToDevice, st));
+            HIPCHK(h, hipMemcpyAsync(dst + from_carry, in + (h->L - from_in),
+                                     (size_t)from_in * sizeof(float2), hipMemcpyDeviceToDevice,
+                                     st));
+            h->cparity ^= 1;
+        }
+        h->carry_len = new0;
+        gsdr_vna_helper_update(&h->vh);  // :382
+        ret = valid;
+    }
+    h->last_index = (h->last_index + (unsigned long long)h->L) % h->cs.period;  // :355
+    return ret;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *gsdr_last_error(const gsdr_demod *h) {
+    return h ? h->err.c_str() : g_create_error.c_str();
+}
+
+gsdr_demod *gsdr_demod_create(const gsdr_param_c *p) {
+    g_create_error.clear();
+    if (!p) {
+        g_create_error = "null parameters";
+        return nullptr;
+    }
+    gsdr_demod *h = new gsdr_demod();
+
+    // ---- mode selection, ref: USRP_demodulator.cpp:15-39 ----
+    int last = GSDR_NODSP;
+    if (p->n_wave_type > 0 && p->wave_type) last = p->wave_type[0];
+    bool mixed = false;
+    int chirps = 0;
+    for (int i = 0; i < p->n_wave_type; ++i) {
+        if (p->wave_type[i] != last) mixed = true;
+        if (p->wave_type[i] == GSDR_CHIRP) chirps++;
+    }
+    if (chirps > 1) {
+        fail_create(h, "Multiple chirp RX buffer demodulation has been requested. This feature is not implemented yet.");
+        return nullptr;
+    }
+    if (mixed) {
+        fail_create(h, "Mixed RX buffer demodulation has been requested. This feature is not implemented yet.");
+        return nullptr;
+    }
+    h->mode = last;
+    h->N = p->n_wave_type;
+    h->L = p->buffer_len;
+    h->decim = p->decim;
+    if (h->L <= 0) {
+        fail_create(h, "buffer_len must be positive");
+        return nullptr;
+    }
+
+    {
+        h->device = p->device_index;
+        if (h->device >= 0 && hipSetDevice(h->device) != hipSuccess) {
+            fail_create(h, "hipSetDevice failed (no such GPU?)");
+            return nullptr;
+        }
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        // ref: :41-44 low priority stream for tone modes, :186-189 high for chirp
+        hipError_t e = hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking,
+                                                   last == GSDR_CHIRP ? hi : lo);
+        if (e != hipSuccess) {
+            h->stream = nullptr;
+            fail_create(h, std::string("cannot create a HIP stream: ") + hipGetErrorString(e));
+            return nullptr;
+        }
+    }
+
+    auto need = [&](bool ok, const char *msg) {
+        if (!ok) fail_create(h, msg);
+        return ok;
+    };
+
+    int rc = 0;
+    switch (last) {
+        case GSDR_DIRECT: {  // ref: :59-119
+            if (!need(p->rate > 0, "rate must be positive")) return nullptr;
+            if (!need(p->n_freq >= h->N && p->freq, "DIRECT needs one frequency per wave_type entry")) return nullptr;
+            std::vector<long long> tone(p->freq, p->freq + h->N);
+            if (h->decim > 0) {
+                if (!need(h->L % h->decim == 0, "buffer_len must be a multiple of decim (ref: fir.cu:20)")) return nullptr;
+                if (!need(p->pf_average >= 1 && p->pf_average <= kMaxF, "pf_average must be in [1,8] for DIRECT with decimation")) return nullptr;
+                if (!need(h->decim <= 0x7fffffffLL / p->pf_average, "decim*pf_average overflows")) return nullptr;
+                const int F = (int)p->pf_average, M = (int)h->decim;
+                h->window.resize((size_t)M * F);
+                // ref: :99 taps, cut-off 0.75/(2*decim) narrowed to float
+                gsdr_make_sinc_window(M * F, (float)(0.75 / (M * 2)), h->window.data());
+                h->kernel_name = gsdr::ddc_kernel_name();
+                rc = setup_ddc_common(h, F, M, (unsigned)p->rate, tone, (int)(h->L / M));
+                if (!rc) {
+                    for (int i = 0; i < 2 && !rc; ++i) {
+                        const size_t n = (size_t)(F > 1 ? F - 1 : 1) * h->Npad;
+                        if (dev_alloc(&h->d_carry[i], n) != hipSuccess ||
+                            hipMemset(h->d_carry[i], 0, n * sizeof(float2)) != hipSuccess) {
+                            h->err = "carry allocation failed";
+                            rc = -1;
+                        }
+                    }
+                }
+                h->capacity = (long long)h->N * (h->L / M);
+            } else {
+                // undecimated: only the NCO tables are needed
+                h->F = 1;
+                h->M = 1;
+                h->window.assign(1, 1.f);
+                h->kernel_name = gsdr::mix_kernel_name();
+                rc = setup_ddc_common(h, 1, 1, (unsigned)p->rate, tone, 1);
+                h->capacity = (long long)h->N * h->L;
+            }
+            break;
+        }
+        case GSDR_TONES: {  // ref: :121-175, :702-768
+            if (!need(p->rate > 0, "rate must be positive")) return nullptr;
+            if (!need(p->fft_tones >= 1, "fft_tones must be >= 1")) return nullptr;
+            if (!need(p->pf_average >= 1 && p->pf_average <= kMaxF, "pf_average must be in [1,8] for TONES")) return nullptr;
+            if (!need(p->n_freq >= h->N && p->freq, "TONES needs one frequency per wave_type entry")) return nullptr;
+            if (!need(h->decim <= 0,
+                      "TONES with decim > 0 is not supported: the reference path is broken "
+                      "(ref: kernels.cu:779, USRP_demodulator.cpp:172,516)")) return nullptr;
+            if (!need((long long)p->fft_tones * p->pf_average <= 0x7fffffffLL, "fft_tones*pf_average overflows")) return nullptr;
+            h->nfft = p->fft_tones;
+            const int F = (int)p->pf_average;
+            h->fcut = (float)(1. / (2 * h->nfft));                     // :131
+            h->window.resize((size_t)h->nfft * F);
+            gsdr_make_sinc_window(h->nfft * F, h->fcut, h->window.data());  // :134
+            h->batching = gsdr_pfb_batching(h->L, h->nfft, F);         // :706
+            h->bins.resize(h->N);
+            gsdr_pfb_tone_bins(p->rate, h->nfft, p->freq, h->N, h->bins.data());  // :722-733
+            std::vector<long long> tone(h->N);
+            for (int u = 0; u < h->N; ++u) tone[u] = h->bins[u] < 0 ? 0 : h->bins[u];
+            gsdr_buffer_helper_init(&h->bh, h->nfft, (int)h->L, F, h->N);  // :159
+            h->kernel_name = gsdr::ddc_kernel_name();
+            rc = setup_ddc_common(h, F, h->nfft, (unsigned)h->nfft, tone,
+                                  (int)(h->L / h->nfft) + F + 6);
+            if (!rc) {
+                // raw_input (:143) plus an equally long scratch half for the carry move
+                const size_t n = (size_t)h->nfft * h->batching * 2;
+                if (dev_alloc(&h->d_raw, n) != hipSuccess ||
+                    hipMemset(h->d_raw, 0, n * sizeof(float2)) != hipSuccess) {
+                    h->err = "raw_input allocation failed";
+                    rc = -1;
+                }
+            }
+            h->capacity = (long long)h->N * h->batching;               // :147
+            break;
+        }
+        case GSDR_CHIRP: {  // ref: :177-262
+            if (!need(p->rate > 0, "rate must be positive")) return nullptr;
+            if (!need(p->n_freq >= 1 && p->n_chirp_f >= 1 && p->n_swipe_s >= 1 && p->n_chirp_t >= 1 &&
+                          p->freq && p->chirp_f && p->swipe_s && p->chirp_t,
+                      "CHIRP needs freq[0], chirp_f[0], swipe_s[0] and chirp_t[0]")) return nullptr;
+            gsdr_chirp_param cp;
+            gsdr_chirp_derive(p->rate, p->freq[0], p->chirp_f[0], p->swipe_s[0], p->chirp_t[0], &cp);
+            if (!need(cp.num_steps >= 1 && cp.length >= 1 &&
+                          cp.num_steps <= 0x7fffffffffffffffULL / cp.length,
+                      "chirp period overflows")) return nullptr;
+            h->cs.num_steps = cp.num_steps;
+            h->cs.length = cp.length;
+            h->cs.period = cp.num_steps * cp.length;
+            h->cs.chirpness = cp.chirpness;
+            h->cs.f0 = cp.f0;
+            if (h->decim > 0) {
+                const unsigned long long ppt = cp.length * (unsigned long long)h->decim;  // :231
+                if (!need(ppt >= 1 && ppt <= (unsigned long long)h->L,
+                          "chirp lock-in needs length*decim <= buffer_len")) return nullptr;
+                h->ppt = (int)ppt;
+                gsdr_vna_helper_init(&h->vh, h->ppt, (int)h->L);       // :235
+                h->window.resize(h->ppt);
+                gsdr_make_flat_window(h->ppt, h->ppt / 10, h->window.data());  // :246
+                h->kernel_name = gsdr::chirp_lockin_kernel_name();
+                if (upload(&h->d_profile, h->window) != hipSuccess ||
+                    dev_alloc(&h->d_ccarry[0], (size_t)h->ppt) != hipSuccess ||
+                    dev_alloc(&h->d_ccarry[1], (size_t)h->ppt) != hipSuccess) {
+                    h->err = "chirp allocation failed";
+                    rc = -1;
+                }
+                h->capacity = h->L / h->ppt + 1;
+            } else {
+                h->kernel_name = gsdr::chirp_demod_kernel_name();
+                h->capacity = h->L;
+            }
+            break;
+        }
+        case GSDR_NODSP:  // ref: :315-321
+            h->capacity = h->L;
+            h->kernel_name = "memcpy";
+            break;
+        case GSDR_NOISE:
+            fail_create(h, "NOISE (full-spectrum PFB) demodulation is not implemented in this build");
+            return nullptr;
+        default:  // ref: :322-325
+            fail_create(h, "Void demodulation operation has not been implemented yet!");
+            return nullptr;
+    }
+    if (rc) {
+        fail_create(h, h->err.empty() ? "device setup failed" : h->err);
+        return nullptr;
+    }
+    return h;
+}
+
+int gsdr_demod_process_device(gsdr_demod *h, const gsdr_c64 *in_dev, gsdr_c64 *out_dev,
+                              void *hip_stream) {
+    if (!h) return -1;
+    if (!in_dev || !out_dev) {
+        h->err = "null buffer";
+        return -1;
+    }
+    if (h->device >= 0) HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->stream;
+    const float2 *in = reinterpret_cast<const float2 *>(in_dev);
+    float2 *out = reinterpret_cast<float2 *>(out_dev);
+    switch (h->mode) {
+        case GSDR_DIRECT: return enqueue_direct(h, in, out, st);
+        case GSDR_TONES: return enqueue_pfb(h, in, out, st);
+        case GSDR_CHIRP: return enqueue_chirp(h, in, out, st);
+        case GSDR_NODSP:  // ref: process_nodsp :335-339
+            HIPCHK(h, hipMemcpyAsync(out, in, (size_t)h->L * sizeof(float2),
+                                     hipMemcpyDeviceToDevice, st));
+            return (int)h->L;
+        default: h->err = "unsupported mode"; return -1;
+    }
+}
+
+int gsdr_demod_process(gsdr_demod *h, const gsdr_c64 *in_host, gsdr_c64 *out_host) {
+    if (!h) return -1;
+    if (!in_host || !out_host) {
+        h->err = "null buffer";
+        return -1;
+    }
+    if (h->mode == GSDR_NODSP) {  // ref: :335-339, a host memcpy
+        std::memcpy(out_host, in_host, (size_t)h->L * sizeof(gsdr_c64));
+        return (int)h->L;
+    }
+    if (h->device >= 0) HIPCHK(h, hipSetDevice(h->device));
+    if (!h->d_in) {
+        HIPCHK(h, dev_alloc(&h->d_in, (size_t)h->L));
+        HIPCHK(h, dev_alloc(&h->d_out, (size_t)h->capacity));
+    }
+    HIPCHK(h, hipMemcpyAsync(h->d_in, in_host, (size_t)h->L * sizeof(float2),
+                             hipMemcpyHostToDevice, h->stream));
+    const int ret = gsdr_demod_process_device(h, reinterpret_cast<gsdr_c64 *>(h->d_in),
+                                              reinterpret_cast<gsdr_c64 *>(h->d_out), h->stream);
+    if (ret < 0) return ret;
+    if (ret > 0)
+        HIPCHK(h, hipMemcpyAsync(out_host, h->d_out, (size_t)ret * sizeof(float2),
+                                 hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // ref: :393,:462,:555
+    return ret;
+}
+
+void gsdr_demod_close(gsdr_demod *h) {
+    if (!h) return;
+    if (h->device >= 0) (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto &e : h->ev_pool) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    void *ptrs[] = {h->d_in,      h->d_out,     h->d_taps_t,   h->d_btab,     h->d_wk,
+                    h->d_wrem,    h->d_fmod,    h->d_tails,    h->d_carry[0], h->d_carry[1],
+                    h->d_raw,     h->d_profile, h->d_ccarry[0], h->d_ccarry[1]};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (h->stream) (void)hipStreamDestroy(h->stream);  // ref: 03_implement.md:58-63
+    delete h;
+}
+
+int gsdr_demod_mode(const gsdr_demod *h) { return h ? h->mode : -1; }
+int gsdr_demod_channels(const gsdr_demod *h) { return h ? h->N : 0; }
+long long gsdr_demod_out_capacity(const gsdr_demod *h) { return h ? h->capacity : 0; }
+float gsdr_demod_fcut(const gsdr_demod *h) { return h ? h->fcut : 0.f; }
+
+int gsdr_demod_get_window(const gsdr_demod *h, float *w, int cap) {
+    if (!h) return 0;
+    const int n = (int)h->window.size();
+    if (w)
+        for (int i = 0; i < n && i < cap; ++i) w[i] = h->window[i];
+    return n;
+}
+
+int gsdr_demod_get_bins(const gsdr_demod *h, int *bins, int cap) {
+    if (!h) return 0;
+    const int n = (int)h->bins.size();
+    if (bins)
+        for (int i = 0; i < n && i < cap; ++i) bins[i] = h->bins[i];
+    return n;
+}
+
+void gsdr_demod_profile_enable(gsdr_demod *h, int enable) {
+    if (!h) return;
+    h->prof = enable != 0;
+    h->ev_used = 0;
+}
+
+int gsdr_demod_profile_read(gsdr_demod *h, double *total_ms) {
+    if (total_ms) *total_ms = 0.0;
+    if (!h || h->ev_used == 0) return 0;
+    if (h->device >= 0) (void)hipSetDevice(h->device);
+    double sum = 0.0;
+    int n = 0;
+    for (size_t i = 0; i < h->ev_used; ++i) {
+        if (hipEventSynchronize(h->ev_pool[i].second) != hipSuccess) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, h->ev_pool[i].first, h->ev_pool[i].second) == hipSuccess) {
+            sum += ms;
+            n++;
+        }
+    }
+    if (total_ms) *total_ms = sum;
+    return n;
+}
+
+const char *gsdr_demod_kernel_name(const gsdr_demod *h) { return h ? h->kernel_name : "none"; }
+
+// ---- synthetic sources -----------------------------------------------------
+int gsdr_source_tones(gsdr_c64 *out_dev, long long n, long long start, int rate, const int *freq,
+                      const float *ampl, const float *phase, int n_tones, float sigma,
+                      unsigned long long seed, void *hip_stream) {
+    if (!out_dev || n < 0 || rate <= 0 || n_tones < 0) return -1;
+    std::vector<unsigned> fm(n_tones > 0 ? n_tones : 1, 0u);
+    for (int k = 0; k < n_tones; ++k) {
+        long long r = (long long)freq[k] % rate;
+        if (r < 0) r += rate;
+        fm[k] = (unsigned)r;
+    }
+    unsigned *d_f = nullptr;
+    float *d_a = nullptr, *d_p = nullptr;
+    const size_t cnt = fm.size();
+    hipError_t e = hipMalloc((void **)&d_f, cnt * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_a, cnt * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_p, cnt * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(d_f, fm.data(), cnt * sizeof(unsigned), hipMemcpyHostToDevice);
+    if (e == hipSuccess && n_tones > 0) e = hipMemcpy(d_a, ampl, n_tones * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess && n_tones > 0) e = hipMemcpy(d_p, phase, n_tones * sizeof(float), hipMemcpyHostToDevice);
+    hipStream_t st = (hipStream_t)hip_stream;
+    long long start_mod = start % rate;
+    if (start_mod < 0) start_mod += rate;
+    if (e == hipSuccess)
+        e = gsdr::launch_source_tones(reinterpret_cast<float2 *>(out_dev), n, start_mod, (unsigned)rate,
+                                      d_f, d_a, d_p, n_tones, sigma, seed, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (d_f) (void)hipFree(d_f);
+    if (d_a) (void)hipFree(d_a);
+    if (d_p) (void)hipFree(d_p);
+    if (e != hipSuccess) {
+        g_create_error = std::string("gsdr_source_tones: ") + hipGetErrorString(e);
+        return -1;
+    }
+    return 0;
+}
+
+int gsdr_source_chirp(gsdr_c64 *out_dev, long long n, unsigned long long last_index,
+                      const gsdr_chirp_param *cp, float scale, void *hip_stream) {
+    if (!out_dev || !cp || n < 0 || cp->num_steps < 1 || cp->length < 1) return -1;
+    ChirpShape cs{};
+    cs.num_steps = cp->num_steps;
+    cs.length = cp->length;
+    cs.period = cp->num_steps * cp->length;
+    cs.chirpness = cp->chirpness;
+    cs.f0 = cp->f0;
+    hipError_t e = gsdr::launch_source_chirp(reinterpret_cast<float2 *>(out_dev), n,
+                                             last_index % cs.period, cs, scale,
+                                             (hipStream_t)hip_stream);
+    if (e != hipSuccess) {
+        g_create_error = std::string("gsdr_source_chirp: ") + hipGetErrorString(e);
+        return -1;
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,176 @@
+/*
+ * gsdr.h -- C ABI of libgsdr.so, the MI355X-native RX demodulation engine.
+ *
+ * Drop-in boundary for the demodulation path of zjc263/GPU_SDR
+ * (RX_buffer_demodulator, /root/reference/headers/USRP_demodulator.hpp:13-33).
+ * Plain pointers and sizes only; no HIP, torch or C++ types cross this header.
+ * The C++ class of the same name that the reference's server code compiles
+ * against is provided header-only on top of this ABI in
+ * include/USRP_demodulator.hpp; INTEGRATION.md shows the binding.
+ *
+ * Citations "ref:" are relative to /root/reference.
+ */
+#ifndef GSDR_H
+#define GSDR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSDR_ABI_VERSION 1
+
+/* complex64, layout-identical to CUDA/HIP float2 (x = re, y = im).
+ * ref: every buffer in headers/USRP_demodulator.hpp is float2*. */
+typedef struct gsdr_c64 { float x, y; } gsdr_c64;
+
+/* ref: headers/USRP_server_settings.hpp:114  enum w_type */
+enum gsdr_w_type {
+    GSDR_TONES = 0, GSDR_CHIRP = 1, GSDR_NOISE = 2, GSDR_RAMP = 3,
+    GSDR_NODSP = 4, GSDR_SWONLY = 5, GSDR_DIRECT = 6
+};
+
+/* Flattened view of the fields of `struct param` that the demodulator reads.
+ * ref: headers/USRP_server_settings.hpp:130-167 (same names, same meaning).
+ * Vectors become (pointer, count) pairs; the pointers are only read during
+ * gsdr_demod_create(). */
+typedef struct gsdr_param_c {
+    int rate;                 /* param::rate  [samples/s]                     */
+    long long decim;          /* param::decim (size_t)                        */
+    int fft_tones;            /* param::fft_tones                             */
+    long long pf_average;     /* param::pf_average (size_t)                   */
+    long long buffer_len;     /* param::buffer_len (size_t)                   */
+    const int *wave_type;     /* param::wave_type, values of gsdr_w_type      */
+    int n_wave_type;
+    const int *freq;          /* param::freq [Hz]                             */
+    int n_freq;
+    const float *chirp_t;     /* param::chirp_t [s]                           */
+    int n_chirp_t;
+    const int *chirp_f;       /* param::chirp_f [Hz]                          */
+    int n_chirp_f;
+    const int *swipe_s;       /* param::swipe_s                               */
+    int n_swipe_s;
+    int device_index;         /* server_settings::GPU_device_index
+                                 (ref: USRP_server_settings.hpp:197); -1 =
+                                 keep the calling thread's current device     */
+} gsdr_param_c;
+
+typedef struct gsdr_demod gsdr_demod;
+
+/* ---- demodulator lifecycle (replaces RX_buffer_demodulator) ------------- */
+
+/* ref: RX_buffer_demodulator::RX_buffer_demodulator, cpp/USRP_demodulator.cpp:7-327.
+ * Returns NULL on failure; gsdr_last_error(NULL) then holds the reason.  Where
+ * the reference calls exit(-1) (mixed wave types :36-39, more than one CHIRP
+ * :31-34, unsupported type :322-325) this returns NULL with the same message. */
+gsdr_demod *gsdr_demod_create(const gsdr_param_c *p);
+
+/* ref: RX_buffer_demodulator::process, cpp/USRP_demodulator.cpp:330.
+ * in_host : buffer_len complex64 (host, pinned or pageable), not modified.
+ * out_host: room for gsdr_demod_out_capacity() complex64.
+ * Synchronous like the reference (returns after the stream has drained).
+ * Returns the number of valid complex samples written to out_host
+ * ([sample][channel] interleaved), or -1 on a device error. */
+int gsdr_demod_process(gsdr_demod *h, const gsdr_c64 *in_host, gsdr_c64 *out_host);
+
+/* Same contract with DEVICE pointers, enqueued on `hip_stream` (a hipStream_t
+ * passed as void*; NULL = the demodulator's own stream) and NOT synchronised:
+ * the returned length is known on the host before the kernels finish.  This
+ * is the entry the synthetic in-HBM source and bench.py use. */
+int gsdr_demod_process_device(gsdr_demod *h, const gsdr_c64 *in_dev,
+                              gsdr_c64 *out_dev, void *hip_stream);
+
+/* ref: RX_buffer_demodulator::close, cpp/USRP_demodulator.cpp:333 (+ :466-698).
+ * Frees every device allocation and the stream, then the handle itself. */
+void gsdr_demod_close(gsdr_demod *h);
+
+/* Last error text of a handle, or of the calling thread's last failed
+ * gsdr_demod_create() when h == NULL.  Never NULL. */
+const char *gsdr_last_error(const gsdr_demod *h);
+
+/* ---- introspection ------------------------------------------------------ */
+int gsdr_abi_version(void);
+/* gsdr_w_type actually dispatched (ref: USRP_demodulator.cpp:19-25,56). */
+int gsdr_demod_mode(const gsdr_demod *h);
+/* parameters->wave_type.size(), what rx_single_link stores in
+ * RX_wrapper.channels (ref: cpp/USRP_server_link_threads.cpp:657). */
+int gsdr_demod_channels(const gsdr_demod *h);
+/* Upper bound of the value process() can return for this configuration. */
+long long gsdr_demod_out_capacity(const gsdr_demod *h);
+/* RX_buffer_demodulator::fcut (ref: USRP_demodulator.cpp:131). */
+float gsdr_demod_fcut(const gsdr_demod *h);
+/* Copies the FIR taps / PFB window / VNA profile in use (real part) into w
+ * (up to cap floats); returns its length. */
+int gsdr_demod_get_window(const gsdr_demod *h, float *w, int cap);
+/* TONES: copies the tone->FFT-bin table (ref: USRP_demodulator.cpp:726-733). */
+int gsdr_demod_get_bins(const gsdr_demod *h, int *bins, int cap);
+
+/* Per-kernel device timing of the dominant kernel with hipEvents recorded on
+ * the launch stream.  enable != 0 starts a fresh accumulation. */
+void gsdr_demod_profile_enable(gsdr_demod *h, int enable);
+/* Synchronises the recorded events; returns the number of timed launches and
+ * their summed duration in milliseconds. */
+int gsdr_demod_profile_read(gsdr_demod *h, double *total_ms);
+/* Name of the dominant kernel for the active mode (as rocprofv3 reports it). */
+const char *gsdr_demod_kernel_name(const gsdr_demod *h);
+
+/* ---- host-side pieces of the path (usable without a GPU) ---------------- */
+/* ref: make_sinc_window, cpp/kernels.cu:258-310 (real part; imag is 0). */
+void gsdr_make_sinc_window(int length, float fc, float *w);
+/* ref: make_flat_window, cpp/kernels.cu:208-253. */
+void gsdr_make_flat_window(int length, int side, float *w);
+
+/* ref: class buffer_helper, cpp/USRP_server_memory_management.cpp:104-156,
+ * headers/USRP_server_memory_management.hpp:77-101 (same field names). */
+typedef struct gsdr_buffer_helper {
+    int n_tones, eff_length, buffer_len, average, n_eff_tones;
+    int new_0, copy_size, current_batch, spare_samples, spare_begin;
+} gsdr_buffer_helper;
+void gsdr_buffer_helper_init(gsdr_buffer_helper *b, int n_tones, int buffer_len,
+                             int average, int n_eff_tones);
+void gsdr_buffer_helper_update(gsdr_buffer_helper *b);
+
+/* ref: class VNA_decimator_helper, cpp/USRP_server_memory_management.cpp:30-56. */
+typedef struct gsdr_vna_helper {
+    int valid_size, new0, total_len, spare_begin, ppt, buffer_len;
+} gsdr_vna_helper;
+void gsdr_vna_helper_init(gsdr_vna_helper *v, int ppt, int buffer_len);
+void gsdr_vna_helper_update(gsdr_vna_helper *v);
+
+/* ref: upload_multitone_parameters, cpp/USRP_demodulator.cpp:722-733.
+ * bins[u] = -1 when no bin matches (the reference leaves it uninitialised). */
+void gsdr_pfb_tone_bins(int rate, int fft_tones, const int *freq, int n, int *bins);
+/* ref: cpp/USRP_demodulator.cpp:706 */
+int gsdr_pfb_batching(long long buffer_len, int fft_tones, long long pf_average);
+
+/* ref: struct chirp_parameter, headers/kernels.cuh:58-64 and its derivation
+ * in cpp/USRP_demodulator.cpp:192-214. */
+typedef struct gsdr_chirp_param {
+    unsigned long long num_steps, length;
+    unsigned int chirpness;
+    int f0;
+} gsdr_chirp_param;
+void gsdr_chirp_derive(int rate, int freq0, int chirp_f, int swipe_s,
+                       float chirp_t, gsdr_chirp_param *cp);
+
+/* ---- synthetic in-memory IQ source (replaces the UHD hardware manager for
+ * benchmarking; shaped after software_rx_thread, ref:
+ * cpp/USRP_hardware_manager.cpp:1331-1395) ------------------------------- */
+/* Fills out_dev[0..n) on the device with
+ *   sum_k ampl[k]*exp(i*(2*pi*freq[k]*((start+j) mod rate)/rate + phase[k]))
+ *   + sigma*(g1 + i*g2)         (g: counter-based unit gaussians from `seed`)
+ * freq/ampl/phase are HOST arrays of n_tones entries. Asynchronous on stream. */
+int gsdr_source_tones(gsdr_c64 *out_dev, long long n, long long start, int rate,
+                      const int *freq, const float *ampl, const float *phase,
+                      int n_tones, float sigma, unsigned long long seed,
+                      void *hip_stream);
+/* TX chirp law (ref: chirp_gen, cpp/kernels.cu:335-372) written to device. */
+int gsdr_source_chirp(gsdr_c64 *out_dev, long long n, unsigned long long last_index,
+                      const gsdr_chirp_param *cp, float scale, void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSDR_H */

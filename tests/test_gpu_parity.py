@@ -1,0 +1,427 @@
+"""GPU parity tests: the HIP path, called through the C ABI (libgsdr.so), against
+the CPU oracle on the same seeded inputs, against the frozen fixtures in
+tests/golden/, and -- at BASELINE.json's full sizes -- against the oracle on a
+subset of tones plus size-independent properties.
+
+Bar (north_star): per tone ||y - y_ref||_2 / ||y_ref||_2 <= 1e-5 (float32), and
+exact equality of every returned length.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+TOL = 1e-5
+
+
+def crandn(rng, n):
+    return (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+
+
+def rel_err_per_tone(y, yr):
+    y = np.asarray(y, dtype=np.complex128)
+    yr = np.asarray(yr, dtype=np.complex128)
+    num = np.linalg.norm(y - yr, axis=0)
+    den = np.linalg.norm(yr, axis=0)
+    return num / np.where(den == 0, 1.0, den)
+
+
+def run_host(dem, x):
+    """host-pointer entry (gsdr_demod_process), synchronous like the reference"""
+    out = np.empty(dem.out_capacity, dtype=np.complex64)
+    n = dem.process(np.ascontiguousarray(x), out)
+    return out[:n].copy()
+
+
+def run_device(dem, x, dev):
+    """device-pointer entry (gsdr_demod_process_device) on the current torch stream"""
+    import torch
+    xin = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    out = torch.empty(dem.out_capacity, dtype=torch.complex64, device=dev)
+    n = dem.process(xin, out)
+    torch.cuda.synchronize()
+    return out[:n].cpu().numpy()
+
+
+def make_direct(freq, rate, decim, f, L):
+    import gpu_sdr_amd as g
+    p = g.param(mode="RX", rate=rate, buffer_len=L, decim=decim, pf_average=f,
+                freq=[int(v) for v in freq], wave_type=[g.w_type.DIRECT] * len(freq))
+    return g.RX_buffer_demodulator(p, device_index=0)
+
+
+def make_pfb(freq, rate, nfft, avg, L):
+    import gpu_sdr_amd as g
+    p = g.param(mode="RX", rate=rate, buffer_len=L, decim=0, pf_average=avg, fft_tones=nfft,
+                freq=[int(v) for v in freq], wave_type=[g.w_type.TONES] * len(freq))
+    return g.RX_buffer_demodulator(p, device_index=0)
+
+
+def make_chirp(rate, f0, f1, steps, t, decim, L):
+    import gpu_sdr_amd as g
+    p = g.param(mode="RX", rate=rate, buffer_len=L, decim=decim, freq=[f0], chirp_f=[f1],
+                swipe_s=[steps], chirp_t=[t], wave_type=[g.w_type.CHIRP])
+    return g.RX_buffer_demodulator(p, device_index=0)
+
+
+# ---------------------------------------------------------------------------
+# frozen fixtures
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["direct", "pfb", "chirp"])
+@pytest.mark.parametrize("entry", ["host", "device"])
+def test_golden_fixture(cuda_device, gsdr_lib, name, entry):
+    g = np.load(os.path.join(HERE, "golden", f"{name}.npz"), allow_pickle=False)
+    cfg = json.loads(str(g["config"]))
+    L = cfg["buffer_len"]
+    if name == "direct":
+        dem = make_direct(cfg["freq"], cfg["rate"], cfg["decim"], cfg["pf_average"], L)
+        nch = len(cfg["freq"])
+    elif name == "pfb":
+        dem = make_pfb(cfg["freq"], cfg["rate"], cfg["fft_tones"], cfg["pf_average"], L)
+        nch = len(cfg["freq"])
+    else:
+        dem = make_chirp(cfg["rate"], cfg["freq"], cfg["chirp_f"], cfg["swipe_s"], cfg["chirp_t"], cfg["decim"], L)
+        nch = 1
+    x = g["x"]
+    outs = []
+    for c in range(len(x) // L):
+        xb = x[c * L:(c + 1) * L]
+        outs.append(run_host(dem, xb) if entry == "host" else run_device(dem, xb, cuda_device))
+    dem.close()
+    assert [len(o) for o in outs] == list(g["lengths"])
+    y = np.concatenate(outs).reshape(-1, nch)
+    yr = g["y"].reshape(-1, nch)
+    assert rel_err_per_tone(y, yr).max() <= TOL
+
+
+# ---------------------------------------------------------------------------
+# DIRECT (DDC)
+# ---------------------------------------------------------------------------
+DIRECT_CASES = [
+    # N, rate, M, F, L, buffers
+    (3, 1_000_000, 50, 4, 50_000, 4),        # survey probe shape, MIN_USEFULL_BUFFER
+    (8, 1_000_000, 100, 1, 50_000, 3),       # single tap phase: no carry
+    (1, 1000, 10, 8, 1000, 5),               # NCO index wraps every buffer, F = 8
+    (65, 10_000_000, 100, 4, 10_000, 3),     # 2 tone waves, one almost empty; M % 16 = 4
+    (5, 1000, 50, 4, 100, 7),                # fewer blocks (2) than F-1: carry outlives a buffer
+    (7, 200_000_000, 1000, 4, 50_000, 3),    # C3 block shape
+    (16, 100_000_000, 100, 4, 100_000, 3),   # C1 shape (16 tones @ 100 Msps, decim 100)
+    (4, 1_000_000, 16, 2, 4096, 3),          # M == K, no remainder
+    (4, 1_000_000, 7, 3, 7000, 3),           # M < K: remainder path only
+    (6, 1_000_000, 37, 5, 37_000, 2),        # odd everything
+]
+
+
+@pytest.mark.parametrize("case", DIRECT_CASES, ids=lambda c: "N%d_M%d_F%d_L%d" % (c[0], c[2], c[3], c[4]))
+@pytest.mark.parametrize("k", [16, 32])
+def test_direct_parity(cuda_device, gsdr_lib, oracle_mod, monkeypatch, case, k):
+    N, rate, M, F, L, nbuf = case
+    monkeypatch.setenv("GSDR_DDC_K", str(k))
+    rng = np.random.default_rng(1000 + N + M)
+    freq = rng.choice(np.arange(-rate // 2 + 1, rate // 2), size=N, replace=False)
+    if N >= 3:
+        freq[0], freq[1], freq[2] = 0, rate // 2 - 1, -(rate // 2) + 1
+    dem = make_direct(freq, rate, M, F, L)
+    ref = oracle_mod.Direct(freq, rate, M, F, L)
+    np.testing.assert_array_equal(dem.window(), ref.taps())
+    for c in range(nbuf):
+        x = crandn(rng, L)
+        y = (run_host if c % 2 else run_device)(dem, x, *(() if c % 2 else (cuda_device,)))
+        yr = ref.process(x)
+        assert y.size == yr.size == N * (L // M)
+        err = rel_err_per_tone(y.reshape(-1, N), yr)
+        assert err.max() <= TOL, (c, err.max())
+    dem.close()
+
+
+def test_direct_streaming_equals_one_long_buffer(cuda_device, gsdr_lib):
+    """Concatenated per-buffer outputs == one call on the concatenated input."""
+    rate, M, F, N = 1_000_000, 100, 4, 9
+    rng = np.random.default_rng(5)
+    freq = rng.integers(-rate // 2 + 1, rate // 2, size=N)
+    x = crandn(rng, 60_000)
+    a = make_direct(freq, rate, M, F, 60_000)
+    ya = run_device(a, x, cuda_device).reshape(-1, N)
+    a.close()
+    b = make_direct(freq, rate, M, F, 20_000)
+    yb = np.concatenate([run_device(b, x[c * 20_000:(c + 1) * 20_000], cuda_device) for c in range(3)]).reshape(-1, N)
+    b.close()
+    assert rel_err_per_tone(yb, ya).max() <= 2e-6
+
+
+def test_direct_undecimated(cuda_device, gsdr_lib, oracle_mod):
+    rng = np.random.default_rng(6)
+    for N, rate, L in [(3, 1000, 1000), (70, 1_000_000, 5000), (5, 200_000_000, 4099)]:
+        freq = rng.integers(-rate // 2 + 1, rate // 2, size=N)
+        dem = make_direct(freq, rate, 0, 4, L)
+        ref = oracle_mod.Direct(freq, rate, 0, 4, L)
+        for c in range(3):
+            x = crandn(rng, L)
+            y = run_device(dem, x, cuda_device) if c != 1 else run_host(dem, x)
+            yr = ref.process(x)
+            assert y.size == N * L
+            assert rel_err_per_tone(y.reshape(-1, N), yr).max() <= 2e-6
+        dem.close()
+
+
+def test_direct_pure_tones_demodulate_to_their_phasors(cuda_device, gsdr_lib):
+    """Closed form, no oracle: a comb demodulates to a_k e^{i phi_k} (DC gain of h is 1)."""
+    from gpu_sdr_amd.source import host_tones
+    rate, L, M, F, N = 10_000_000, 100_000, 100, 4, 12
+    freq = (np.arange(N) - N // 2) * 400_000 + 12_345  # >= 4 output bandwidths apart
+    ampl = np.linspace(0.02, 0.08, N).astype(np.float32)
+    phase = np.linspace(0, 6, N).astype(np.float32)
+    dem = make_direct(freq, rate, M, F, L)
+    ys = []
+    for c in range(2):
+        ys.append(run_device(dem, host_tones(L, c * L, rate, freq, ampl, phase), cuda_device).reshape(-1, N))
+    dem.close()
+    y = np.concatenate(ys)[F:]
+    want = ampl * np.exp(1j * phase.astype(np.float64))
+    assert np.abs(y - want).max() < 5e-4  # stop-band leakage of the other tones
+
+
+# ---------------------------------------------------------------------------
+# TONES (PFB)
+# ---------------------------------------------------------------------------
+PFB_CASES = [
+    # N, rate, nfft, avg, L, buffers
+    (3, 1000, 10, 4, 103, 6),                # survey probe shape
+    (3, 1_000_000, 10, 4, 50_000, 3),
+    (6, 1_000_000, 100, 1, 50_000, 3),
+    (8, 1_000_000, 100, 4, 50_000, 4),
+    (5, 200_000_000, 1000, 4, 50_123, 4),    # nfft does not divide L
+    (4, 200_000_000, 1230, 4, 100_000, 3),   # the client's typical odd nfft
+    (2, 1000, 64, 8, 300, 6),                # buffer shorter than the window: empty outputs
+    (70, 10_000_000, 128, 2, 20_000, 3),
+]
+
+
+@pytest.mark.parametrize("case", PFB_CASES, ids=lambda c: "N%d_nfft%d_avg%d_L%d" % (c[0], c[2], c[3], c[4]))
+def test_pfb_parity(cuda_device, gsdr_lib, oracle_mod, case):
+    N, rate, nfft, avg, L, nbuf = case
+    rng = np.random.default_rng(2000 + nfft + avg)
+    freq = rng.integers(-rate // 2 + 1, rate // 2, size=N)
+    freq[0] = 0
+    dem = make_pfb(freq, rate, nfft, avg, L)
+    ref = oracle_mod.Pfb(freq, rate, nfft, avg, L)
+    np.testing.assert_array_equal(dem.bins(), ref.bins())
+    np.testing.assert_array_equal(dem.window(),
+                                  oracle_mod.make_sinc_window(nfft * avg, np.float32(1. / (2 * nfft))))
+    assert dem.out_capacity == N * ref.batching
+    emitted = 0
+    for c in range(nbuf):
+        x = crandn(rng, L)
+        y = (run_host if c % 2 else run_device)(dem, x, *(() if c % 2 else (cuda_device,)))
+        yr = ref.process(x)
+        assert y.size == yr.size, (c, y.size, yr.size)
+        emitted += len(yr)
+        if len(yr):
+            err = rel_err_per_tone(y.reshape(-1, N), yr)
+            assert err.max() <= TOL, (c, err.max())
+    assert emitted > 0
+    dem.close()
+
+
+# ---------------------------------------------------------------------------
+# CHIRP (VNA)
+# ---------------------------------------------------------------------------
+CHIRP_CASES = [
+    # rate, f0, f1, steps, chirp_t, decim, L, buffers
+    (200_000_000, -90_000_000, 90_000_000, 1000, 3.5e-5, 0, 5000, 3),   # survey probe, undecimated
+    (200_000_000, -90_000_000, 90_000_000, 1000, 3.5e-5, 1, 5000, 4),   # ppt 7, remainder 2
+    (1_000_000, -100_000, 100_000, 50, 0.00035, 2, 500, 5),             # ppt 14
+    (200_000_000, -100_000_000, 100_000_000, 1_000_000, 1.0, 1, 50_000, 3),   # C4: ppt 200
+    (200_000_000, -100_000_000, 100_000_000, 1_000_000, 1.5, 1, 50_000, 4),   # C4 variant: ppt 300, carry
+    (200_000_000, 50_000_000, -50_000_000, 300, 3e-4, 0, 60_000, 2),    # downward sweep (wrapping chirpness)
+    (200_000_000, -100_000_000, 100_000_000, 1_000_000, 30.0, 0, 20_000, 2),  # period > 2^32: 64-bit path
+    (200_000_000, -100_000_000, 100_000_000, 1_000_000, 30.0, 1, 20_000, 3),  # same with lock-in, ppt 6000
+    (1_000_000, -400_000, 400_000, 10, 1e-5, 3, 1000, 3),               # length 1, ppt 3 < 64 lanes
+]
+
+
+@pytest.mark.parametrize("case", CHIRP_CASES,
+                         ids=lambda c: "steps%d_t%g_dec%d_L%d" % (c[3], c[4], c[5], c[6]))
+def test_chirp_parity(cuda_device, gsdr_lib, oracle_mod, case):
+    rate, f0, f1, steps, t, decim, L, nbuf = case
+    rng = np.random.default_rng(3000 + steps + decim)
+    dem = make_chirp(rate, f0, f1, steps, t, decim, L)
+    ref = oracle_mod.Chirp(rate, f0, f1, steps, t, decim, L)
+    for c in range(nbuf):
+        x = crandn(rng, L)
+        y = (run_host if c % 2 else run_device)(dem, x, *(() if c % 2 else (cuda_device,)))
+        yr = ref.process(x)
+        assert y.size == yr.size, (c, y.size, yr.size)
+        assert rel_err_per_tone(y[:, None], yr[:, None]).max() <= TOL
+    dem.close()
+
+
+def test_chirp_loopback_constant_phasor(cuda_device, gsdr_lib):
+    """TX law -> RX law gives a constant phasor (no oracle)."""
+    import torch
+    import gpu_sdr_amd as g
+    from gpu_sdr_amd.source import device_chirp
+    rate, L = 200_000_000, 1_000_000
+    cp = g.chirp_derive(rate, -100_000_000, 100_000_000, 1_000_000, 1.0)
+    dem = make_chirp(rate, -100_000_000, 100_000_000, 1_000_000, 1.0, 1, L)
+    x = torch.empty(L, dtype=torch.complex64, device=cuda_device)
+    out = torch.empty(dem.out_capacity, dtype=torch.complex64, device=cuda_device)
+    last = 0
+    for c in range(3):
+        device_chirp(x, last, cp, scale=0.5)
+        n = dem.process(x, out)
+        torch.cuda.synchronize()
+        assert n == 5000
+        y = out[:n].cpu().numpy()
+        # flat window drops the first ppt/10 samples and averages the rest: gain 1
+        np.testing.assert_allclose(y, 0.5 + 0j, rtol=0, atol=2e-6)
+        last += L
+    dem.close()
+
+
+# ---------------------------------------------------------------------------
+# full BASELINE.json sizes
+# ---------------------------------------------------------------------------
+def _full_size_direct(cuda_device, oracle_mod, N, M, nbuf, subset):
+    import torch
+    from gpu_sdr_amd.source import device_tones, tone_comb
+    rate, L, F = 200_000_000, 1_000_000, 4
+    freq, ampl, phase = tone_comb(N, rate, seed=20251004)
+    dem = make_direct(freq, rate, M, F, L)
+    rng = np.random.default_rng(9)
+    pick = np.unique(np.concatenate([[0, 63, 64, N - 1], rng.integers(0, N, size=subset)]))
+    ref = oracle_mod.Direct(freq[pick], rate, M, F, L)
+    x = torch.empty(L, dtype=torch.complex64, device=cuda_device)
+    out = torch.empty(dem.out_capacity, dtype=torch.complex64, device=cuda_device)
+    for c in range(nbuf):
+        # start near the end of a second so that the NCO index wraps inside the run
+        start = rate - L - 12345 + c * L
+        device_tones(x, start, rate, freq, ampl, phase, sigma=1e-3, seed=77 + c)
+        if c == 0:
+            # the demodulator's index starts at 0: feed it the same phase origin
+            pass
+        n = dem.process(x, out)
+        torch.cuda.synchronize()
+        assert n == N * (L // M)
+        y = out[:n].cpu().numpy().reshape(-1, N)
+        assert np.isfinite(y.view(np.float32)).all()
+        yr = ref.process(x.cpu().numpy())
+        err = rel_err_per_tone(y[:, pick], yr)
+        assert err.max() <= TOL, (c, err.max())
+    dem.close()
+
+
+def test_c2_256_tones_decim100_full_size(cuda_device, gsdr_lib, oracle_mod):
+    _full_size_direct(cuda_device, oracle_mod, N=256, M=100, nbuf=3, subset=12)
+
+
+def test_c3_2048_tones_decim1000_full_size(cuda_device, gsdr_lib, oracle_mod):
+    _full_size_direct(cuda_device, oracle_mod, N=2048, M=1000, nbuf=3, subset=12)
+
+
+def test_c3_linearity_all_tones(cuda_device, gsdr_lib):
+    """Size-independent property over ALL 2048 tones at full size:
+    demod(a + b) == demod(a) + demod(b)."""
+    import torch
+    from gpu_sdr_amd.source import tone_comb
+    rate, L, M, F, N = 200_000_000, 1_000_000, 1000, 4, 2048
+    freq, _, _ = tone_comb(N, rate, seed=3)
+    gen = torch.Generator(device=cuda_device).manual_seed(11)
+    a = torch.view_as_complex(torch.randn(L, 2, device=cuda_device, generator=gen))
+    b = torch.view_as_complex(torch.randn(L, 2, device=cuda_device, generator=gen))
+    ys = []
+    for x in (a, b, a + b):
+        dem = make_direct(freq, rate, M, F, L)
+        out = torch.empty(dem.out_capacity, dtype=torch.complex64, device=cuda_device)
+        n = dem.process(x.contiguous(), out)
+        torch.cuda.synchronize()
+        ys.append(out[:n].clone().reshape(-1, N))
+        dem.close()
+    num = torch.linalg.vector_norm(ys[2] - (ys[0] + ys[1]), dim=0)
+    den = torch.linalg.vector_norm(ys[2], dim=0)
+    assert float((num / den).max()) <= 5e-6
+
+
+def test_c4_chirp_vna_full_size(cuda_device, gsdr_lib, oracle_mod):
+    """1e6-point sweep over 200 MHz, 1 M-sample buffers, lock-in ppt = 200."""
+    import torch
+    import gpu_sdr_amd as g
+    from gpu_sdr_amd.source import device_chirp
+    rate, L = 200_000_000, 1_000_000
+    args = (rate, -100_000_000, 100_000_000, 1_000_000, 1.0)
+    cp = g.chirp_derive(*args)
+    dem = make_chirp(*args, 1, L)
+    ref = oracle_mod.Chirp(*args, 1, L)
+    x = torch.empty(L, dtype=torch.complex64, device=cuda_device)
+    out = torch.empty(dem.out_capacity, dtype=torch.complex64, device=cuda_device)
+    gen = torch.Generator(device=cuda_device).manual_seed(4)
+    for c in range(3):
+        device_chirp(x, c * L, cp, scale=0.3)
+        x += 1e-3 * torch.view_as_complex(torch.randn(L, 2, device=cuda_device, generator=gen))
+        n = dem.process(x, out)
+        torch.cuda.synchronize()
+        yr = ref.process(x.cpu().numpy())
+        assert n == len(yr) == 5000
+        y = out[:n].cpu().numpy()
+        assert rel_err_per_tone(y[:, None], yr[:, None]).max() <= TOL
+    dem.close()
+
+
+# ---------------------------------------------------------------------------
+# sources, passthrough, error paths
+# ---------------------------------------------------------------------------
+def test_device_sources_match_their_formulas(cuda_device, gsdr_lib, oracle_mod):
+    import torch
+    import gpu_sdr_amd as g
+    from gpu_sdr_amd.source import device_chirp, device_tones, host_tones, tone_comb
+    rate, n = 1_000_000, 20_000
+    freq, ampl, phase = tone_comb(5, rate, seed=2)
+    x = torch.empty(n, dtype=torch.complex64, device=cuda_device)
+    device_tones(x, rate - 7000, rate, freq, ampl, phase, sigma=0.0)
+    np.testing.assert_allclose(x.cpu().numpy(), host_tones(n, rate - 7000, rate, freq, ampl, phase),
+                               rtol=0, atol=3e-6)
+    device_tones(x, 0, rate, freq, ampl, phase, sigma=0.1, seed=5)
+    noise = x.cpu().numpy() - host_tones(n, 0, rate, freq, ampl, phase)
+    assert abs(noise.real.std() - 0.1) < 0.005 and abs(noise.imag.std() - 0.1) < 0.005
+    assert abs(noise.mean()) < 0.005
+    cp = g.chirp_derive(200_000_000, -90_000_000, 90_000_000, 1000, 3.5e-5)
+    ocp = oracle_mod.chirp_params(200_000_000, -90_000_000, 90_000_000, 1000, 3.5e-5)
+    device_chirp(x, 6500, cp, scale=0.5)
+    np.testing.assert_allclose(x.cpu().numpy(), oracle_mod.chirp_gen(ocp, 6500, n, 0.5), rtol=0, atol=3e-7)
+
+
+def test_nodsp_passthrough(cuda_device, gsdr_lib):
+    import gpu_sdr_amd as g
+    rng = np.random.default_rng(8)
+    p = g.param(rate=1000, buffer_len=500, wave_type=[])
+    dem = g.RX_buffer_demodulator(p, device_index=0)
+    assert dem.mode == g.w_type.NODSP
+    x = crandn(rng, 500)
+    np.testing.assert_array_equal(run_host(dem, x), x)
+    np.testing.assert_array_equal(run_device(dem, x, cuda_device), x)
+    dem.close()
+
+
+def test_unsupported_requests_fail_loudly(cuda_device, gsdr_lib):
+    import gpu_sdr_amd as g
+    base = dict(rate=1_000_000, buffer_len=1000, freq=[1, 2])
+    with pytest.raises(g.GsdrError, match="not supported"):
+        g.RX_buffer_demodulator(g.param(decim=2, fft_tones=10, wave_type=[g.w_type.TONES] * 2, **base), device_index=0)
+    with pytest.raises(g.GsdrError, match="multiple of decim"):
+        g.RX_buffer_demodulator(g.param(decim=7, wave_type=[g.w_type.DIRECT] * 2, **base), device_index=0)
+    with pytest.raises(g.GsdrError, match="pf_average"):
+        g.RX_buffer_demodulator(g.param(decim=10, pf_average=9, wave_type=[g.w_type.DIRECT] * 2, **base), device_index=0)
+    with pytest.raises(g.GsdrError, match="NOISE"):
+        g.RX_buffer_demodulator(g.param(fft_tones=10, wave_type=[g.w_type.NOISE], **base), device_index=0)
+    with pytest.raises(g.GsdrError, match="Void demodulation"):
+        g.RX_buffer_demodulator(g.param(wave_type=[g.w_type.RAMP], **base), device_index=0)
+
+
+def test_native_library_is_the_one_loaded(cuda_device, gsdr_lib):
+    """Guards against a silent fallback: the in-tree libgsdr.so must be mapped."""
+    maps = open("/proc/self/maps").read()
+    assert "gpu_sdr_amd/libgsdr.so" in maps

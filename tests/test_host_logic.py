@@ -1,0 +1,171 @@
+"""CPU tests of libgsdr.so's host-side logic against the oracle, and of the
+C-ABI surface (every symbol include/gsdr.h declares must be exported).
+No GPU compute here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(gsdr_lib):
+    hdr = open(os.path.join(ROOT, "include", "gsdr.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(gsdr_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    from gpu_sdr_amd import _lib
+    bound = {name for name, _, _ in _lib.SIGNATURES}
+    assert declared == bound, (declared - bound, bound - declared)
+    for name in declared:
+        assert hasattr(gsdr_lib, name), name
+    assert gsdr_lib.gsdr_abi_version() == 1
+
+
+def test_cpp_shim_header_compiles_with_gxx(tmp_path):
+    """include/USRP_demodulator.hpp is what the reference's server code would
+    include instead of its CUDA class: it must compile with plain g++."""
+    src = tmp_path / "t.cpp"
+    src.write_text('#include "USRP_demodulator.hpp"\n'
+                   "int main(){ param p; p.buffer_len = 100; p.rate = 1000; p.decim = 0;\n"
+                   " p.wave_type.push_back(NODSP); RX_wrapper w; (void)w;\n"
+                   " return sizeof(RX_buffer_demodulator) > 0 ? 0 : 1; }\n")
+    import subprocess
+    subprocess.check_call(["g++", "-std=c++11", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)])
+
+
+@pytest.mark.parametrize("length,fc", [(40, 0.0375), (400, 0.75 / 200), (4000, 0.75 / 2000),
+                                        (41, 0.0375), (30, 1. / 20), (12, 1. / 6), (1, 0.1), (2, 0.25)])
+def test_sinc_window_bit_exact(gsdr_lib, oracle_mod, length, fc):
+    import gpu_sdr_amd as g
+    np.testing.assert_array_equal(g.make_sinc_window(length, np.float32(fc)),
+                                  oracle_mod.make_sinc_window(length, np.float32(fc)))
+
+
+@pytest.mark.parametrize("length,side", [(20, 2), (200, 20), (7, 0), (300, 30), (10, 1)])
+def test_flat_window_bit_exact(gsdr_lib, oracle_mod, length, side):
+    import gpu_sdr_amd as g
+    np.testing.assert_array_equal(g.make_flat_window(length, side), oracle_mod.make_flat_window(length, side))
+
+
+def test_buffer_helper_exhaustive_small(gsdr_lib, oracle_mod):
+    import gpu_sdr_amd as g
+    for nfft in (1, 2, 3, 7, 10, 16, 33):
+        for avg in (1, 2, 4, 5):
+            for L in (1, 5, 50, 103, 128, 1000):
+                a = g.buffer_helper(nfft, L, avg, 3)
+                b = oracle_mod.BufferHelper(nfft, L, avg, 3)
+                for _ in range(12):
+                    assert a.state() == b.state(), (nfft, avg, L)
+                    a.update()
+                    b.update()
+
+
+def test_buffer_helper_baseline_shapes(gsdr_lib, oracle_mod):
+    import gpu_sdr_amd as g
+    for nfft, avg, L in [(1230, 4, 1_000_000), (1000, 4, 1_000_000), (100, 8, 1_000_000), (65536, 2, 1_000_000)]:
+        a = g.buffer_helper(nfft, L, avg, 256)
+        b = oracle_mod.BufferHelper(nfft, L, avg, 256)
+        consumed = 0
+        for _ in range(40):
+            assert a.state() == b.state()
+            consumed += a.current_batch
+            a.update()
+            b.update()
+        # no frame is lost or duplicated: frames emitted == floor((40 L - avg*nfft)/nfft)+1 or one less
+        assert abs(consumed - ((40 * L - avg * nfft - 1) // nfft + 1)) <= 1
+
+
+def test_vna_helper_exhaustive_small(gsdr_lib, oracle_mod):
+    import gpu_sdr_amd as g
+    for ppt in (1, 2, 7, 14, 200, 300, 999):
+        for L in (1000, 1001, 5000):
+            a = g.VNA_decimator_helper(ppt, L)
+            b = oracle_mod.VnaHelper(ppt, L)
+            total = 0
+            for c in range(15):
+                assert a.state() == b.state()
+                total += a.valid_size
+                a.update()
+                b.update()
+            assert total == (15 * L) // ppt
+
+
+def test_tone_bins_match_literal_scan(gsdr_lib, oracle_mod):
+    import gpu_sdr_amd as g
+    rng = np.random.default_rng(7)
+    for rate, nfft in [(1000, 10), (1200, 12), (200_000_000, 1230), (100_000_000, 1000),
+                       (200_000_000, 65536), (1000, 7), (999, 9), (200_000_000, 3)]:
+        f = rng.integers(-rate // 2 - rate // nfft, rate // 2 + rate // nfft, size=300).astype(np.int32)
+        bs = rate / nfft
+        centres = (np.arange(nfft) * bs - bs * (nfft // 2))
+        extra = np.concatenate([centres[:50], centres[-50:], centres[:20] + 1, centres[:20] - 1])
+        f = np.concatenate([f, np.round(extra).astype(np.int32)])
+        np.testing.assert_array_equal(g.pfb_tone_bins(rate, nfft, f), oracle_mod.pfb_tone_bins(rate, nfft, f))
+    assert g.pfb_batching(1_000_000, 1230, 4) == oracle_mod.pfb_batching(1_000_000, 1230, 4) == 823
+
+
+def test_chirp_derive_matches_oracle(gsdr_lib, oracle_mod):
+    import gpu_sdr_amd as g
+    cases = [(200_000_000, -100_000_000, 100_000_000, 1_000_000, 1.0),
+             (200_000_000, -100_000_000, 100_000_000, 1_000_000, 1.5),
+             (200_000_000, -90_000_000, 90_000_000, 1000, 3.5e-5),
+             (100_000_000, 10_000_000, -40_000_000, 5000, 0.01),   # downward sweep: wraps
+             (1_000_000, -100_000, 100_000, 0, 0.001),             # swipe_s < 1 -> chirp_t*rate steps
+             (1_000_000, 0, 0, 1, 0.001),                          # single step: division by zero slope
+             (200_000_000, 200_000_000, 100_000_000, 100, 1e-9)]   # f0 overflow, length clamp
+    for c in cases:
+        a, b = g.chirp_derive(*c), oracle_mod.chirp_params(*c)
+        assert (a.num_steps, a.length, a.chirpness, a.f0) == (b.num_steps, b.length, b.chirpness, b.f0), c
+
+
+def _param_c(**kw):
+    from gpu_sdr_amd import _lib
+    keep = []
+    pc = _lib.ParamC()
+    for k in ("rate", "decim", "fft_tones", "pf_average", "buffer_len"):
+        setattr(pc, k, kw.get(k, 0))
+    for name, ct in (("wave_type", C.c_int), ("freq", C.c_int), ("chirp_t", C.c_float),
+                     ("chirp_f", C.c_int), ("swipe_s", C.c_int)):
+        vals = kw.get(name, [])
+        arr = (ct * max(len(vals), 1))(*vals)
+        keep.append(arr)
+        setattr(pc, name, C.cast(arr, C.POINTER(ct)))
+        setattr(pc, "n_" + name, len(vals))
+    pc.device_index = -1
+    return pc, keep
+
+
+def test_create_rejects_what_the_reference_exits_on(gsdr_lib):
+    """Mode checks happen before any device call (ref: USRP_demodulator.cpp:27-39)."""
+    pc, keep = _param_c(rate=1000, buffer_len=100, wave_type=[6, 0], freq=[1, 2])
+    assert not gsdr_lib.gsdr_demod_create(C.byref(pc))
+    assert b"Mixed RX buffer demodulation" in gsdr_lib.gsdr_last_error(None)
+    pc, keep = _param_c(rate=1000, buffer_len=100, wave_type=[1, 1], freq=[1, 2])
+    assert not gsdr_lib.gsdr_demod_create(C.byref(pc))
+    assert b"Multiple chirp" in gsdr_lib.gsdr_last_error(None)
+    assert not gsdr_lib.gsdr_demod_create(None)
+
+
+def test_python_mirror_raises_with_reference_message(gsdr_lib):
+    import gpu_sdr_amd as g
+    p = g.param(rate=1000, buffer_len=100, wave_type=[g.w_type.DIRECT, g.w_type.TONES], freq=[1, 2])
+    with pytest.raises(g.GsdrError, match="Mixed RX buffer demodulation"):
+        g.RX_buffer_demodulator(p)
+    assert g.string_to_w_type("DIRECT") == g.w_type.DIRECT
+    assert g.string_to_w_type("RAMP") == g.w_type.NODSP  # not parsed by the reference
+    assert g.string_to_w_type("bogus") == g.w_type.NODSP
+    assert g.w_type_to_str(g.w_type.CHIRP) == "CHIRP"
+
+
+def test_no_cpu_fallback_in_product():
+    """The product package must never import the oracle."""
+    pkg = os.path.join(ROOT, "gpu_sdr_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, f
+                assert "gsdr_oracle" not in txt and "liboracle" not in txt, f
