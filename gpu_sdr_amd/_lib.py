@@ -99,6 +99,11 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own HIP runtime (torch/lib/libamdhip64.so, same SONAME as
+    # the system one libgsdr.so is linked against).  Whichever copy is mapped
+    # first serves both, and torch only works with its own: load torch first so
+    # that device pointers, streams and this library share ONE runtime.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise GsdrLibraryError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "

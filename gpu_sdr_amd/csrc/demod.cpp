@@ -563,7 +563,7 @@ int gsdr_demod_process_device(gsdr_demod *h, const gsdr_c64 *in_dev, gsdr_c64 *o
         return -1;
     }
     if (h->device >= 0) HIPCHK(h, hipSetDevice(h->device));
-    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->stream;
+    hipStream_t st = (hipStream_t)hip_stream;  // NULL is HIP's null stream, as everywhere in HIP
     const float2 *in = reinterpret_cast<const float2 *>(in_dev);
     float2 *out = reinterpret_cast<float2 *>(out_dev);
     switch (h->mode) {

@@ -76,8 +76,10 @@ gsdr_demod *gsdr_demod_create(const gsdr_param_c *p);
 int gsdr_demod_process(gsdr_demod *h, const gsdr_c64 *in_host, gsdr_c64 *out_host);
 
 /* Same contract with DEVICE pointers, enqueued on `hip_stream` (a hipStream_t
- * passed as void*; NULL = the demodulator's own stream) and NOT synchronised:
- * the returned length is known on the host before the kernels finish.  This
+ * passed as void*; NULL = HIP's null stream, as in every HIP call) and NOT
+ * synchronised: the caller orders it against the producer of in_dev and the
+ * consumer of out_dev through that stream.
+ * The returned length is known on the host before the kernels finish.  This
  * is the entry the synthetic in-HBM source and bench.py use. */
 int gsdr_demod_process_device(gsdr_demod *h, const gsdr_c64 *in_dev,
                               gsdr_c64 *out_dev, void *hip_stream);
@@ -161,7 +163,8 @@ void gsdr_chirp_derive(int rate, int freq0, int chirp_f, int swipe_s,
 /* Fills out_dev[0..n) on the device with
  *   sum_k ampl[k]*exp(i*(2*pi*freq[k]*((start+j) mod rate)/rate + phase[k]))
  *   + sigma*(g1 + i*g2)         (g: counter-based unit gaussians from `seed`)
- * freq/ampl/phase are HOST arrays of n_tones entries. Asynchronous on stream. */
+ * freq/ampl/phase are HOST arrays of n_tones entries.  Returns after the
+ * kernel has finished on `hip_stream` (setup helper, not part of the hot path). */
 int gsdr_source_tones(gsdr_c64 *out_dev, long long n, long long start, int rate,
                       const int *freq, const float *ampl, const float *phase,
                       int n_tones, float sigma, unsigned long long seed,
