@@ -16,11 +16,13 @@ struct DdcShape {
     unsigned rate;             // NCO modulus (sample rate, or nfft for TONES)
     unsigned long long idx0;   // NCO index of x[0] (mod rate)
     long long total;           // mix_kernel only: number of samples
+    long long xlast;           // ddc_flat_kernel: x[0 .. xlast+2) is readable
 };
 
 struct DdcLaunch {
     const float2 *x;
-    const float *taps_t;
+    const float *taps_t;    // [M][F]                 (ddc_kernel)
+    const float *taps_p;    // [nsub*PK+2][FP] zero padded (ddc_flat_kernel), FP = 1,2,4
     const float2 *btab;
     const double2 *wk;
     const double2 *wrem;
@@ -30,16 +32,20 @@ struct DdcLaunch {
     const float2 *carry_in;
     float2 *carry_out;
     DdcShape sh;
+    bool pipe;              // use ddc_flat_kernel (F <= 4, phasor table length K in {12,16,20})
 };
 
-// F = tap phases (pf_average, 1..8), K = phasor-table length (16 or 32).
+// F = tap phases (pf_average, 1..8), K = phasor-table length (16 or 32; 12/16/20
+// when a.pipe selects ddc_flat_kernel).
 // Enqueues ddc_kernel<F,K> and, when F > 1, ddc_fixup.  `stop` (may be null)
 // is recorded right after ddc_kernel, before the fixup.
 hipError_t launch_ddc(int F, int K, const DdcLaunch &a, hipStream_t st, hipEvent_t stop);
 // Undecimated DIRECT (decim == 0).
 hipError_t launch_mix(int K, const DdcLaunch &a, hipStream_t st);
 
+hipError_t launch_ddc_flat_main(int F, int PK, const DdcLaunch &a, hipStream_t st);
 const char *ddc_kernel_name();
+const char *ddc_flat_kernel_name();
 const char *mix_kernel_name();
 
 // ---- chirp ---------------------------------------------------------------

@@ -284,7 +284,8 @@ static hipError_t launch_ddc_k(int F, const DdcLaunch &a, hipStream_t st) {
 
 hipError_t launch_ddc(int F, int K, const DdcLaunch &a, hipStream_t st, hipEvent_t stop) {
     hipError_t e;
-    if (K == 16) e = launch_ddc_k<16>(F, a, st);
+    if (a.pipe) e = launch_ddc_flat_main(F, K, a, st);
+    else if (K == 16) e = launch_ddc_k<16>(F, a, st);
     else if (K == 32) e = launch_ddc_k<32>(F, a, st);
     else return hipErrorInvalidValue;
     if (e != hipSuccess) return e;

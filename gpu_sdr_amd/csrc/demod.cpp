@@ -62,6 +62,10 @@ struct gsdr_demod {
     int nch_max = 1;
     std::vector<float> window;         // taps (DIRECT) / PFB window / VNA profile, real part
     float *d_taps_t = nullptr;
+    float *d_taps_p = nullptr;         // zero-padded [nsub*K+2][FP] copy for ddc_flat_kernel
+    bool pipe = false;                 // ddc_flat_kernel (F <= 4) instead of ddc_kernel
+    int pad = 0;                       // samples the flat kernel reads past a block (nsub*K - M)
+    float2 *d_stage = nullptr;         // padded copy of the input when pad > 0 (DIRECT only)
     float2 *d_btab = nullptr;
     double2 *d_wk = nullptr, *d_wrem = nullptr;
     unsigned *d_fmod = nullptr;
@@ -168,6 +172,13 @@ int upload_taps_transposed(gsdr_demod *h) {
     for (int j = 0; j < h->F; ++j)
         for (int m = 0; m < h->M; ++m) t[(size_t)m * h->F + j] = h->window[(size_t)j * h->M + m];
     HIPCHK(h, upload(&h->d_taps_t, t));
+    if (h->pipe) {
+        const int FP = h->F == 3 ? 4 : h->F;
+        std::vector<float> p((size_t)(h->M + h->pad + 2) * FP, 0.f);
+        for (int j = 0; j < h->F; ++j)
+            for (int m = 0; m < h->M; ++m) p[(size_t)m * FP + j] = h->window[(size_t)j * h->M + m];
+        HIPCHK(h, upload(&h->d_taps_p, p));
+    }
     return 0;
 }
 
@@ -182,19 +193,43 @@ int pick_chunks(const gsdr_demod *h, int nblk) {
 }
 
 int setup_ddc_common(gsdr_demod *h, int F, int M, unsigned rate,
-                     const std::vector<long long> &tone, int max_nblk) {
+                     const std::vector<long long> &tone, int max_nblk, bool allow_flat = true) {
     h->F = F;
     h->M = M;
     h->nco_rate = rate;
     h->Npad = ((h->N + 63) / 64) * 64;
     h->TW = h->Npad / 64;
-    h->K = env_int("GSDR_DDC_K", 16) == 32 ? 32 : 16;
-    h->R = M % h->K;
+    // ddc_flat_kernel (packed math, pipelined scalar loads) covers F <= 4;
+    // ddc_kernel is the generic fallback (and GSDR_DDC_PIPE=0 forces it, for A/B runs)
+    h->pipe = allow_flat && env_int("GSDR_DDC_PIPE", 1) != 0 && F <= 4;
+    if (h->pipe) {
+        // sub-block length: whole sub-blocks per block, cheapest total
+        // (padded samples + ~3.3 sample-equivalents of fold work per sub-block)
+        int forced = env_int("GSDR_DDC_K", 0);
+        if (forced != 12 && forced != 16 && forced != 20) forced = 0;
+        double best = 1e300;
+        for (int k : {20, 16, 12}) {
+            if (forced && forced != k) continue;
+            const long long nsub = (M + k - 1) / k;
+            const double cost = (double)nsub * (k + 3.3);
+            if (cost < best) {
+                best = cost;
+                h->K = k;
+            }
+        }
+        const int nsub = (M + h->K - 1) / h->K;
+        h->pad = nsub * h->K - M;
+        h->R = M - (nsub - 1) * h->K;   // length of the last sub-block in real samples
+    } else {
+        h->K = env_int("GSDR_DDC_K", 16) == 32 ? 32 : 16;
+        h->R = M % h->K;
+    }
     int cus = 256;
     int dev = 0;
     if (hipGetDevice(&dev) == hipSuccess)
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const int wps = env_int("GSDR_DDC_WAVES_PER_SIMD", 4);
+    // resident waves per SIMD of the kernel actually used (VGPR-limited)
+    const int wps = env_int("GSDR_DDC_WAVES_PER_SIMD", h->pipe ? (h->K == 20 ? 5 : 6) : 4);
     h->target_waves = cus * 4 * (wps > 0 ? wps : 4);
     h->nch_max = pick_chunks(h, max_nblk);
     if (build_nco_tables(h, tone, rate)) return -1;
@@ -229,6 +264,8 @@ int enqueue_direct(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t st)
     DdcLaunch a{};
     a.x = in;
     a.taps_t = h->d_taps_t;
+    a.taps_p = h->d_taps_p;
+    a.pipe = h->pipe && h->decim > 0;
     a.btab = h->d_btab;
     a.wk = h->d_wk;
     a.wrem = h->d_wrem;
@@ -249,6 +286,15 @@ int enqueue_direct(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t st)
         a.sh.M = h->M;
         a.sh.nblk = (int)(h->L / h->M);
         a.sh.nch = h->nch_max;
+        a.sh.xlast = h->L - 2;
+        if (a.pipe && h->pad > 0) {
+            // the last sub-block of a block reads `pad` samples past it (zero taps);
+            // behind the last block that would leave the caller's buffer
+            HIPCHK(h, hipMemcpyAsync(h->d_stage, in, (size_t)h->L * sizeof(float2),
+                                     hipMemcpyDeviceToDevice, st));
+            a.x = h->d_stage;
+            a.sh.xlast = h->L + h->pad - 2;
+        }
         if (record_begin(h, st, &stop)) return -1;
         HIPCHK(h, gsdr::launch_ddc(h->F, h->K, a, st, stop));
         h->parity ^= 1;
@@ -280,6 +326,7 @@ int enqueue_pfb(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t st) {
         DdcLaunch a{};
         a.x = h->d_raw;
         a.taps_t = h->d_taps_t;
+        a.taps_p = h->d_taps_p;
         a.btab = h->d_btab;
         a.wk = h->d_wk;
         a.wrem = h->d_wrem;
@@ -295,6 +342,8 @@ int enqueue_pfb(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t st) {
         a.sh.idx0 = 0;          // raw_input[0] is always on the frame grid
         a.sh.M = h->M;
         a.sh.nblk = cb + h->F - 1;  // frame r spans blocks r .. r+F-1
+        a.pipe = h->pipe;
+        a.sh.xlast = (long long)a.sh.nblk * h->M + h->pad - 2;  // d_raw is twice the window
         a.sh.g_off = h->F - 1;      // DDC output G <-> frame r = G-(F-1)
         int nch = pick_chunks(h, a.sh.nblk);
         if (nch > h->nch_max) nch = h->nch_max;
@@ -441,8 +490,16 @@ gsdr_demod *gsdr_demod_create(const gsdr_param_c *p) {
                 h->window.resize((size_t)M * F);
                 // ref: :99 taps, cut-off 0.75/(2*decim) narrowed to float
                 gsdr_make_sinc_window(M * F, (float)(0.75 / (M * 2)), h->window.data());
-                h->kernel_name = gsdr::ddc_kernel_name();
                 rc = setup_ddc_common(h, F, M, (unsigned)p->rate, tone, (int)(h->L / M));
+                if (!rc && h->pipe && h->pad > 0) {
+                    const size_t n = (size_t)h->L + h->pad;
+                    if (dev_alloc(&h->d_stage, n) != hipSuccess ||
+                        hipMemset(h->d_stage, 0, n * sizeof(float2)) != hipSuccess) {
+                        h->err = "staging allocation failed";
+                        rc = -1;
+                    }
+                }
+                h->kernel_name = h->pipe ? gsdr::ddc_flat_kernel_name() : gsdr::ddc_kernel_name();
                 if (!rc) {
                     for (int i = 0; i < 2 && !rc; ++i) {
                         const size_t n = (size_t)(F > 1 ? F - 1 : 1) * h->Npad;
@@ -460,7 +517,7 @@ gsdr_demod *gsdr_demod_create(const gsdr_param_c *p) {
                 h->M = 1;
                 h->window.assign(1, 1.f);
                 h->kernel_name = gsdr::mix_kernel_name();
-                rc = setup_ddc_common(h, 1, 1, (unsigned)p->rate, tone, 1);
+                rc = setup_ddc_common(h, 1, 1, (unsigned)p->rate, tone, 1, /*allow_flat=*/false);
                 h->capacity = (long long)h->N * h->L;
             }
             break;
@@ -485,9 +542,9 @@ gsdr_demod *gsdr_demod_create(const gsdr_param_c *p) {
             std::vector<long long> tone(h->N);
             for (int u = 0; u < h->N; ++u) tone[u] = h->bins[u] < 0 ? 0 : h->bins[u];
             gsdr_buffer_helper_init(&h->bh, h->nfft, (int)h->L, F, h->N);  // :159
-            h->kernel_name = gsdr::ddc_kernel_name();
             rc = setup_ddc_common(h, F, h->nfft, (unsigned)h->nfft, tone,
                                   (int)(h->L / h->nfft) + F + 6);
+            h->kernel_name = h->pipe ? gsdr::ddc_flat_kernel_name() : gsdr::ddc_kernel_name();
             if (!rc) {
                 // raw_input (:143) plus an equally long scratch half for the carry move
                 const size_t n = (size_t)h->nfft * h->batching * 2;
@@ -613,7 +670,7 @@ void gsdr_demod_close(gsdr_demod *h) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
     }
-    void *ptrs[] = {h->d_in,      h->d_out,     h->d_taps_t,   h->d_btab,     h->d_wk,
+    void *ptrs[] = {h->d_in,      h->d_out,     h->d_taps_t,   h->d_taps_p,   h->d_stage,    h->d_btab,     h->d_wk,
                     h->d_wrem,    h->d_fmod,    h->d_tails,    h->d_carry[0], h->d_carry[1],
                     h->d_raw,     h->d_profile, h->d_ccarry[0], h->d_ccarry[1]};
     for (void *p : ptrs)

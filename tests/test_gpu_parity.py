@@ -117,10 +117,13 @@ DIRECT_CASES = [
 
 
 @pytest.mark.parametrize("case", DIRECT_CASES, ids=lambda c: "N%d_M%d_F%d_L%d" % (c[0], c[2], c[3], c[4]))
-@pytest.mark.parametrize("k", [16, 32])
-def test_direct_parity(cuda_device, gsdr_lib, oracle_mod, monkeypatch, case, k):
+@pytest.mark.parametrize("impl", ["flat", "flat12", "flat16", "flat20", "simple16", "simple32"])
+def test_direct_parity(cuda_device, gsdr_lib, oracle_mod, monkeypatch, case, impl):
+    """flat* = ddc_flat_kernel (production; sub-block length auto / forced),
+    simple* = ddc_kernel (generic fallback, phasor table 16 / 32)."""
     N, rate, M, F, L, nbuf = case
-    monkeypatch.setenv("GSDR_DDC_K", str(k))
+    monkeypatch.setenv("GSDR_DDC_PIPE", "1" if impl.startswith("flat") else "0")
+    monkeypatch.setenv("GSDR_DDC_K", impl.lstrip("flatsimple") or "0")
     rng = np.random.default_rng(1000 + N + M)
     freq = rng.choice(np.arange(-rate // 2 + 1, rate // 2), size=N, replace=False)
     if N >= 3:
