@@ -16,7 +16,7 @@ struct DdcShape {
     unsigned rate;             // NCO modulus (sample rate, or nfft for TONES)
     unsigned long long idx0;   // NCO index of x[0] (mod rate)
     long long total;           // mix_kernel only: number of samples
-    long long xlast;           // ddc_flat_kernel: x[0 .. xlast+2) is readable
+    long long xlast;           // ddc_flat_kernel: x[0 .. xlast+4) is readable
 };
 
 struct DdcLaunch {

@@ -58,7 +58,8 @@ struct gsdr_demod {
     int F = 0, K = 16, M = 0, Npad = 0, TW = 0, R = 0;
     unsigned nco_rate = 1;
     unsigned long long idx = 0;        // DIRECT_current_index (ref :88, :437-440)
-    int target_waves = 4096;
+    int target_waves = 4096;           // resident waves the DDC grid is sized for
+    int simds = 1024;                  // SIMDs of the device (4 per CU)
     int nch_max = 1;
     std::vector<float> window;         // taps (DIRECT) / PFB window / VNA profile, real part
     float *d_taps_t = nullptr;
@@ -182,14 +183,33 @@ int upload_taps_transposed(gsdr_demod *h) {
     return 0;
 }
 
+// Number of chunks the blocks of one launch are cut into.  All waves of the grid
+// are resident at once (that is what target_waves is sized for), so the launch
+// takes as long as its longest chunk on its fullest SIMD: prefer grids that are a
+// whole number of 256-workgroup rounds (one wave per SIMD each) with chunks of
+// (almost) equal length, at the highest occupancy that keeps both true.
 int pick_chunks(const gsdr_demod *h, int nblk) {
     if (nblk <= 0) return 1;
-    long long nch = h->target_waves / (h->TW > 0 ? h->TW : 1);
-    if (nch < 1) nch = 1;
+    const int TW = h->TW > 0 ? h->TW : 1;
     const long long cap = (h->F > 1) ? nblk / (h->F - 1) : nblk;  // every chunk >= F-1 blocks
-    if (nch > cap) nch = cap;
-    if (nch < 1) nch = 1;
-    return (int)nch;
+    const int rounds_max = h->target_waves / h->simds > 0 ? h->target_waves / h->simds : 1;
+    long long best_nch = 1;
+    double best = -1.0;
+    for (int r = rounds_max; r >= 1; --r) {
+        long long nch = (long long)r * h->simds / TW;
+        if (nch < 1) nch = 1;
+        if (nch > cap) nch = cap;
+        if (nch < 1) nch = 1;
+        const long long longest = (nblk + nch - 1) / nch;
+        const double balance = ((double)nblk / (double)nch) / (double)longest;
+        const double fill = (double)(nch * TW) / ((double)r * h->simds);   // SIMD slots used
+        const double score = balance * fill * (1.0 - 0.04 * (rounds_max - r));
+        if (score > best) {
+            best = score;
+            best_nch = nch;
+        }
+    }
+    return (int)best_nch;
 }
 
 int setup_ddc_common(gsdr_demod *h, int F, int M, unsigned rate,
@@ -229,8 +249,9 @@ int setup_ddc_common(gsdr_demod *h, int F, int M, unsigned rate,
     if (hipGetDevice(&dev) == hipSuccess)
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     // resident waves per SIMD of the kernel actually used (VGPR-limited)
-    const int wps = env_int("GSDR_DDC_WAVES_PER_SIMD", h->pipe ? (h->K == 20 ? 5 : 6) : 4);
-    h->target_waves = cus * 4 * (wps > 0 ? wps : 4);
+    const int wps = env_int("GSDR_DDC_WAVES_PER_SIMD", h->pipe ? 6 : 4);
+    h->simds = cus * 4;
+    h->target_waves = h->simds * (wps > 0 ? wps : 4);
     h->nch_max = pick_chunks(h, max_nblk);
     if (build_nco_tables(h, tone, rate)) return -1;
     if (upload_taps_transposed(h)) return -1;
@@ -265,7 +286,7 @@ int enqueue_direct(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t st)
     a.x = in;
     a.taps_t = h->d_taps_t;
     a.taps_p = h->d_taps_p;
-    a.pipe = h->pipe && h->decim > 0;
+    a.pipe = h->pipe && h->decim > 0 && h->L >= 4;
     a.btab = h->d_btab;
     a.wk = h->d_wk;
     a.wrem = h->d_wrem;
@@ -286,14 +307,14 @@ int enqueue_direct(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t st)
         a.sh.M = h->M;
         a.sh.nblk = (int)(h->L / h->M);
         a.sh.nch = h->nch_max;
-        a.sh.xlast = h->L - 2;
+        a.sh.xlast = h->L - 4;
         if (a.pipe && h->pad > 0) {
             // the last sub-block of a block reads `pad` samples past it (zero taps);
             // behind the last block that would leave the caller's buffer
             HIPCHK(h, hipMemcpyAsync(h->d_stage, in, (size_t)h->L * sizeof(float2),
                                      hipMemcpyDeviceToDevice, st));
             a.x = h->d_stage;
-            a.sh.xlast = h->L + h->pad - 2;
+            a.sh.xlast = h->L + h->pad - 4;
         }
         if (record_begin(h, st, &stop)) return -1;
         HIPCHK(h, gsdr::launch_ddc(h->F, h->K, a, st, stop));
@@ -343,7 +364,7 @@ int enqueue_pfb(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t st) {
         a.sh.M = h->M;
         a.sh.nblk = cb + h->F - 1;  // frame r spans blocks r .. r+F-1
         a.pipe = h->pipe;
-        a.sh.xlast = (long long)a.sh.nblk * h->M + h->pad - 2;  // d_raw is twice the window
+        a.sh.xlast = (long long)a.sh.nblk * h->M + h->pad - 4;  // d_raw is twice the window
         a.sh.g_off = h->F - 1;      // DDC output G <-> frame r = G-(F-1)
         int nch = pick_chunks(h, a.sh.nblk);
         if (nch > h->nch_max) nch = h->nch_max;
