@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgsdr.so")
+# GSDR_LIB: load a differently built copy (timing-only ablation builds in scratch/)
+LIB_PATH = os.environ.get("GSDR_LIB") or os.path.join(_HERE, "libgsdr.so")
 
 
 class GsdrLibraryError(RuntimeError):

@@ -32,6 +32,7 @@ struct DdcLaunch {
     const float2 *carry_in;
     float2 *carry_out;
     DdcShape sh;
+    unsigned lds_bytes;     // dynamic LDS per workgroup (occupancy cap, see launch_flat_fk)
     bool pipe;              // use ddc_flat_kernel (F <= 4, phasor table length K in {12,16,20})
 };
 

@@ -61,6 +61,8 @@ struct gsdr_demod {
     int target_waves = 4096;           // resident waves the DDC grid is sized for
     int simds = 1024;                  // SIMDs of the device (4 per CU)
     int nch_max = 1;
+    int nch_force = 0;                 // GSDR_DDC_NCH: experiment override
+    unsigned lds_bytes = 0;            // GSDR_DDC_LDS: dummy LDS per workgroup (occupancy cap)
     std::vector<float> window;         // taps (DIRECT) / PFB window / VNA profile, real part
     float *d_taps_t = nullptr;
     float *d_taps_p = nullptr;         // zero-padded [nsub*K+2][FP] copy for ddc_flat_kernel
@@ -183,27 +185,32 @@ int upload_taps_transposed(gsdr_demod *h) {
     return 0;
 }
 
-// Number of chunks the blocks of one launch are cut into.  All waves of the grid
-// are resident at once (that is what target_waves is sized for), so the launch
-// takes as long as its longest chunk on its fullest SIMD: prefer grids that are a
-// whole number of 256-workgroup rounds (one wave per SIMD each) with chunks of
-// (almost) equal length, at the highest occupancy that keeps both true.
+// Number of chunks the blocks of one launch are cut into (one wave per
+// chunk x 64 tones).  Measured on MI355X (gpurun_out/sweep2/3, C2 and C3): wave
+// run times spread widely, so a grid ~1.3x larger than what is resident at once
+// -- the hardware dispatcher hands the surplus workgroups to whichever CU frees
+// up first -- beats an exactly-resident grid, and chunks of EQUAL length beat
+// both.  So: aim at 1.3 x resident waves, and within +-25 % of that prefer the
+// chunk count that splits the blocks most evenly.
 int pick_chunks(const gsdr_demod *h, int nblk) {
     if (nblk <= 0) return 1;
     const int TW = h->TW > 0 ? h->TW : 1;
     const long long cap = (h->F > 1) ? nblk / (h->F - 1) : nblk;  // every chunk >= F-1 blocks
-    const int rounds_max = h->target_waves / h->simds > 0 ? h->target_waves / h->simds : 1;
-    long long best_nch = 1;
+    if (cap < 1) return 1;
+    if (h->nch_force > 0) return (int)(h->nch_force < cap ? h->nch_force : cap);
+    long long want = (long long)(1.3 * h->target_waves) / TW;
+    if (want < 1) want = 1;
+    if (want > cap) want = cap;
+    long long lo = want - want / 4, hi = want + want / 4;
+    if (lo < 1) lo = 1;
+    if (hi > cap) hi = cap;
+    long long best_nch = want;
     double best = -1.0;
-    for (int r = rounds_max; r >= 1; --r) {
-        long long nch = (long long)r * h->simds / TW;
-        if (nch < 1) nch = 1;
-        if (nch > cap) nch = cap;
-        if (nch < 1) nch = 1;
+    for (long long nch = lo; nch <= hi; ++nch) {
         const long long longest = (nblk + nch - 1) / nch;
         const double balance = ((double)nblk / (double)nch) / (double)longest;
-        const double fill = (double)(nch * TW) / ((double)r * h->simds);   // SIMD slots used
-        const double score = balance * fill * (1.0 - 0.04 * (rounds_max - r));
+        const double dist = std::fabs((double)(nch - want)) / (double)want;
+        const double score = balance - 0.02 * dist;
         if (score > best) {
             best = score;
             best_nch = nch;
@@ -252,6 +259,8 @@ int setup_ddc_common(gsdr_demod *h, int F, int M, unsigned rate,
     const int wps = env_int("GSDR_DDC_WAVES_PER_SIMD", h->pipe ? 6 : 4);
     h->simds = cus * 4;
     h->target_waves = h->simds * (wps > 0 ? wps : 4);
+    h->nch_force = env_int("GSDR_DDC_NCH", 0);
+    h->lds_bytes = (unsigned)env_int("GSDR_DDC_LDS", 0);
     h->nch_max = pick_chunks(h, max_nblk);
     if (build_nco_tables(h, tone, rate)) return -1;
     if (upload_taps_transposed(h)) return -1;
@@ -287,6 +296,7 @@ int enqueue_direct(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t st)
     a.taps_t = h->d_taps_t;
     a.taps_p = h->d_taps_p;
     a.pipe = h->pipe && h->decim > 0 && h->L >= 4;
+    a.lds_bytes = h->lds_bytes;
     a.btab = h->d_btab;
     a.wk = h->d_wk;
     a.wrem = h->d_wrem;
@@ -364,6 +374,7 @@ int enqueue_pfb(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t st) {
         a.sh.M = h->M;
         a.sh.nblk = cb + h->F - 1;  // frame r spans blocks r .. r+F-1
         a.pipe = h->pipe;
+        a.lds_bytes = h->lds_bytes;
         a.sh.xlast = (long long)a.sh.nblk * h->M + h->pad - 4;  // d_raw is twice the window
         a.sh.g_off = h->F - 1;      // DDC output G <-> frame r = G-(F-1)
         int nch = pick_chunks(h, a.sh.nblk);
