@@ -31,8 +31,9 @@ def clobbers(x0, t0):
     return ", ".join(f'"s{r}"' for r in list(range(x0, x0 + 8)) + list(range(t0, t0 + 16)))
 
 
-def step(F, FP, cur_is_a, n, lo0, nxt_n, nxt_from_next, nxt_off):
-    """asm text + operand lists of one step."""
+def step(F, FP, cur_is_a, n, lo0, nxt_n, nxt_from_next, nxt_off, first=False):
+    """asm text + operand lists of one step.  first: S is write-only (the very
+    first MAC of the sub-block is a multiply, so S needs no zeroing)."""
     cx, ct = (XA, TA) if cur_is_a else (XB, TB)
     nx, nt = (XB, TB) if cur_is_a else (XA, TA)
     lines = ["@W"]
@@ -49,11 +50,17 @@ def step(F, FP, cur_is_a, n, lo0, nxt_n, nxt_from_next, nxt_off):
         for j in range(F):
             flat = s * FP + j               # index of h[j] of sample s in the tap tuple
             pair = sreg(ct + (flat // 2) * 2, 2)
-            if flat % 2 == 0:
+            if first and s == 0:
+                if flat % 2 == 0:
+                    lines.append(f"v_pk_mul_f32 %[s{j}], {pair}, %[u] op_sel_hi:[0,1]")
+                else:
+                    lines.append(f"v_pk_mul_f32 %[s{j}], {pair}, %[u] op_sel:[1,0] op_sel_hi:[1,1]")
+            elif flat % 2 == 0:
                 lines.append(f"v_pk_fma_f32 %[s{j}], {pair}, %[u], %[s{j}] op_sel_hi:[0,1,1]")
             else:
                 lines.append(f"v_pk_fma_f32 %[s{j}], {pair}, %[u], %[s{j}] op_sel:[1,0,0] op_sel_hi:[1,1,1]")
-    outs = ", ".join([f'[s{j}] "+v"(S[{j}])' for j in range(F)] + ['[t] "=&v"(t)', '[u] "=&v"(u)'])
+    sc = '"=&v"' if first else '"+v"'
+    outs = ", ".join([f'[s{j}] {sc}(S[{j}])' for j in range(F)] + ['[t] "=&v"(t)', '[u] "=&v"(u)'])
     ins = ", ".join([f'[b{s}] "v"(B[{lo0 + s}])' for s in range(n)] +
                     (['[xn] "s"(xnext)', '[tn] "s"(tnext)'] if nxt_from_next else ['[xp] "s"(xg)', '[tp] "s"(tg)']))
     def emit(ln):
@@ -71,6 +78,7 @@ def subblock(F, PK):
     sizes = SIZES[PK]
     assert sum(sizes) == PK and len(sizes) % 2 == 0 and sizes[0] == 4
     out = [f"template <> struct SubBlock<{F}, {PK}> {{",
+           "    // S is an OUTPUT: the sub-block sums start from zero",
            f"    static __device__ __forceinline__ void run(f2v (&S)[{F}], const f2v (&B)[{PK}], const float2 *xg,",
            "                                               const float *tg, const float2 *xnext,",
            "                                               const float *tnext) {",
@@ -79,7 +87,7 @@ def subblock(F, PK):
     for k, n in enumerate(sizes):
         last = (k == len(sizes) - 1)
         nxt_n = sizes[0] if last else sizes[k + 1]
-        out.append(step(F, FP, k % 2 == 0, n, lo, nxt_n, last, lo + n))
+        out.append(step(F, FP, k % 2 == 0, n, lo, nxt_n, last, lo + n, first=(k == 0)))
         lo += n
     out.append("    }\n};\n")
     return "\n".join(out)
