@@ -17,6 +17,7 @@ struct DdcShape {
     unsigned long long idx0;   // NCO index of x[0] (mod rate)
     long long total;           // mix_kernel only: number of samples
     long long xlast;           // ddc_flat_kernel: x[0 .. xlast+4) is readable
+    int prefetch;              // ddc_flat_kernel: LDS-DMA L2 prefetch of the IQ stream on/off
 };
 
 struct DdcLaunch {

@@ -63,6 +63,7 @@ struct gsdr_demod {
     int nch_max = 1;
     int nch_force = 0;                 // GSDR_DDC_NCH: experiment override
     unsigned lds_bytes = 0;            // GSDR_DDC_LDS: dummy LDS per workgroup (occupancy cap)
+    int prefetch = 1;                  // GSDR_DDC_PREFETCH: L2 prefetch of the IQ stream
     std::vector<float> window;         // taps (DIRECT) / PFB window / VNA profile, real part
     float *d_taps_t = nullptr;
     float *d_taps_p = nullptr;         // zero-padded [nsub*K+2][FP] copy for ddc_flat_kernel
@@ -261,6 +262,7 @@ int setup_ddc_common(gsdr_demod *h, int F, int M, unsigned rate,
     h->target_waves = h->simds * (wps > 0 ? wps : 4);
     h->nch_force = env_int("GSDR_DDC_NCH", 0);
     h->lds_bytes = (unsigned)env_int("GSDR_DDC_LDS", 0);
+    h->prefetch = env_int("GSDR_DDC_PREFETCH", 1);
     h->nch_max = pick_chunks(h, max_nblk);
     if (build_nco_tables(h, tone, rate)) return -1;
     if (upload_taps_transposed(h)) return -1;
@@ -297,6 +299,7 @@ int enqueue_direct(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t st)
     a.taps_p = h->d_taps_p;
     a.pipe = h->pipe && h->decim > 0 && h->L >= 4;
     a.lds_bytes = h->lds_bytes;
+    a.sh.prefetch = h->prefetch;
     a.btab = h->d_btab;
     a.wk = h->d_wk;
     a.wrem = h->d_wrem;
@@ -375,6 +378,7 @@ int enqueue_pfb(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t st) {
         a.sh.nblk = cb + h->F - 1;  // frame r spans blocks r .. r+F-1
         a.pipe = h->pipe;
         a.lds_bytes = h->lds_bytes;
+        a.sh.prefetch = h->prefetch;
         a.sh.xlast = (long long)a.sh.nblk * h->M + h->pad - 4;  // d_raw is twice the window
         a.sh.g_off = h->F - 1;      // DDC output G <-> frame r = G-(F-1)
         int nch = pick_chunks(h, a.sh.nblk);

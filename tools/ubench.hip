@@ -131,6 +131,51 @@ __global__ __launch_bounds__(256) void k_valu_ddc(float *out, float s) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
 
+// packed DDC step, as ddc_flat_kernel issues it: per sample 2 + 4 v_pk instructions
+__device__ __forceinline__ void pk_ddc_body(float2v &s0, float2v &s1, float2v &s2, float2v &s3, float2v b, float2v x, float2v h01, float2v h23) {
+    float2v t, u;
+    asm volatile(
+        "v_pk_mul_f32 %[t], %[x], %[b] op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[1,0]\n\t"
+        "v_pk_fma_f32 %[u], %[x], %[b], %[t] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %[s0], %[h01], %[u], %[s0] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %[s1], %[h01], %[u], %[s1] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %[s2], %[h23], %[u], %[s2] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %[s3], %[h23], %[u], %[s3] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+        : [s0] "+v"(s0), [s1] "+v"(s1), [s2] "+v"(s2), [s3] "+v"(s3), [t] "=&v"(t), [u] "=&v"(u)
+        : [b] "v"(b), [x] "s"(x), [h01] "s"(h01), [h23] "s"(h23));
+}
+
+// mode 0: every wave runs the packed VALU DDC body; mode 1: every wave runs f32 MFMA 32x32x2;
+// mode 2: even workgroups run the VALU body, odd ones the MFMA loop (do the two pipes of a SIMD overlap?)
+typedef float float16v __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void k_split(float *out, float s, int mode) {
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const bool do_mfma = mode == 1 || (mode == 2 && ((blockIdx.x >> 8) & 1));  // rounds of 256 workgroups alternate: with round-robin placement every SIMD holds both kinds
+    float r = 0;
+    if (!do_mfma) {
+        float2v s0 = {0, 0}, s1 = {0, 0}, s2 = {0, 0}, s3 = {0, 0};
+        float2v b = {threadIdx.x * 1e-3f + 1.0f, threadIdx.x * 1e-4f + 0.5f};
+        float2v x = {s, s * 0.5f}, h01 = {s * 0.1f, s * 0.2f}, h23 = {s * 0.3f, s * 0.4f};
+        for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) pk_ddc_body(s0, s1, s2, s3, b, x, h01, h23);
+        }
+        r = s0.x + s0.y + s1.x + s1.y + s2.x + s2.y + s3.x + s3.y;
+    } else {
+        float16v acc[2];
+        for (int i = 0; i < 2; ++i)
+            for (int e = 0; e < 16; ++e) acc[i][e] = 0;
+        float a = threadIdx.x * 1e-3f + s, b = threadIdx.x * 1e-4f + 1.0f;
+        for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[k & 1], 0, 0, 0);
+        }
+        for (int i = 0; i < 2; ++i)
+            for (int e = 0; e < 16; ++e) r += acc[i][e];
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+
 // scalar-load stream: each wave walks a buffer with s_load_dwordx16 and folds it into a VGPR
 __global__ __launch_bounds__(256) void k_sload(float *out, const float *__restrict__ buf, int words) {
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -184,6 +229,14 @@ int main() {
         printf("   hybrid   : %.3f T tone-samples/s\n", 8.0 * ITERS * 256.0 * blocks / t / 1e12);
         t = run("valu_ddc", 8 * 22.0, blocks, k_valu_ddc, out, 1.0001f);
         printf("   valu_ddc : %.3f T tone-samples/s\n", 8.0 * ITERS * 256.0 * blocks / t / 1e12);
+        // k_split: VALU waves do 8 samples/iter (48 pk instr); MFMA waves 4 x 32x32x2 (4096 flop each) per iter
+        t = run("split_valu", 8 * 22.0, blocks, k_split, out, 1.0001f, 0);
+        printf("   all-VALU : %.3f T tone-samples/s\n", 8.0 * ITERS * 256.0 * blocks / t / 1e12);
+        t = run("split_mfma", 4 * 4096.0 / 64.0, blocks, k_split, out, 1.0001f, 1);
+        printf("   all-MFMA : %.2f TFLOP/s\n", 4 * 4096.0 / 64.0 * ITERS * 256.0 * blocks / t / 1e12);
+        t = run("split_both", 0.5 * 8 * 22.0 + 0.5 * 4 * 4096.0 / 64.0, blocks, k_split, out, 1.0001f, 2);
+        printf("   half/half: VALU half %.3f T tone-samples/s + MFMA half %.2f TFLOP/s in %.3f ms\n",
+               0.5 * 8.0 * ITERS * 256.0 * blocks / t / 1e12, 0.5 * 4 * 4096.0 / 64.0 * ITERS * 256.0 * blocks / t / 1e12, t * 1e3);
         t = run("sload_x16", 16 * 2.0, blocks, k_sload, out, (const float *)buf, 1 << 20);
         printf("   sload    : %.2f TB/s scalar bytes (64 B per wave per 16 fma)\n",
                64.0 * ITERS * 4.0 * blocks / t / 1e12);
