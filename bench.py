@@ -49,6 +49,10 @@ WORKLOADS = {
     # configs[3]
     "c4": dict(kind="chirp", decim=1, chirp_t=1.0, swipe_s=1_000_000,
                name="Chirp VNA demod (USRP_VNA), 1e6-point sweep over 200 MHz, lock-in ppt=200"),
+    # TONES mode (PFB channelizer + tone select) at array scale: not a BASELINE config
+    # line of its own, but the same DDC kernel with M = nfft, F = pf_average
+    "pfb": dict(kind="pfb", n_tones=1024, fft_tones=1230, pf_average=4, decim=0,
+                name="1024-tone PFB channelizer (TONES), nfft=1230, pf_average=4, 200 Msps"),
     # configs[0] shape on the GPU (the CPU-runnable plumbing case)
     "c1": dict(kind="direct", n_tones=16, decim=100, pf_average=4, rate=100_000_000,
                name="16-tone DDC, decim=100, 100 Msps"),
@@ -114,6 +118,9 @@ def algorithmic(wl, n_tones):
     if wl["kind"] == "direct":
         M, f = wl["decim"], wl["pf_average"]
         return 8.0 * (1.0 + n_tones / M), float(n_tones * (6 + 4 * f))
+    if wl["kind"] == "pfb":
+        M, f = wl["fft_tones"], wl["pf_average"]
+        return 8.0 * (1.0 + n_tones / M), float(n_tones * (6 + 4 * f))
     ppt = 200 * wl["decim"]
     return 8.0 + 8.0 / ppt, 8.0 + 30.0
 
@@ -124,11 +131,16 @@ def build_workload(wl, device, seed, ring=8, n_tones=None):
     from gpu_sdr_amd.source import device_chirp, device_tones, tone_comb
     rate = wl.get("rate", RATE)
     bufs = [torch.empty(L, dtype=torch.complex64, device=device) for _ in range(ring)]
-    if wl["kind"] == "direct":
+    if wl["kind"] in ("direct", "pfb"):
         N = n_tones or wl["n_tones"]
         freq, ampl, phase = tone_comb(N, rate, seed)
-        p = g.param(mode="RX", rate=rate, buffer_len=L, decim=wl["decim"], pf_average=wl["pf_average"],
-                    freq=[int(f) for f in freq], wave_type=[g.w_type.DIRECT] * N)
+        if wl["kind"] == "direct":
+            p = g.param(mode="RX", rate=rate, buffer_len=L, decim=wl["decim"], pf_average=wl["pf_average"],
+                        freq=[int(f) for f in freq], wave_type=[g.w_type.DIRECT] * N)
+        else:
+            p = g.param(mode="RX", rate=rate, buffer_len=L, decim=0, pf_average=wl["pf_average"],
+                        fft_tones=wl["fft_tones"], freq=[int(f) for f in freq],
+                        wave_type=[g.w_type.TONES] * N)
         for i, b in enumerate(bufs):
             device_tones(b, i * L, rate, freq, ampl, phase, sigma=1e-3, seed=seed * 1000 + i)
     else:
@@ -220,6 +232,11 @@ def cpu_baseline_oracle(wl, seed, min_seconds=8.0, max_buffers=6):
         freq, _, _ = tone_comb(N, rate, seed)
         dem = oracle.Direct(freq, rate, wl["decim"], wl["pf_average"], L)
         what = f"{N} tones"
+    elif wl["kind"] == "pfb":
+        N = wl["n_tones"]
+        freq, _, _ = tone_comb(N, rate, seed)
+        dem = oracle.Pfb(freq, rate, wl["fft_tones"], wl["pf_average"], L)
+        what = f"{N} PFB tones"
     else:
         dem = oracle.Chirp(rate, -rate // 2, rate // 2, wl["swipe_s"], wl["chirp_t"], wl["decim"], L)
         what = "chirp lock-in"
@@ -314,7 +331,7 @@ def main():
         roof_hbm = dict(bound="hbm", achieved=round(gbs, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(gbs / HBM_PEAK_GBS, 5), traffic=traffic,
                         kernel=r["kernel"], kernel_us=round(kt * 1e6, 2))
-        if wl["kind"] == "direct":
+        if wl["kind"] in ("direct", "pfb"):
             # fused DDC: ~1800 flop/B, FP32-compute bound. The FP32
             # vector peak equals the FP32 (f32-input) MFMA peak on gfx950: 157.3 TF.
             roof = dict(bound="mfma", pipe="fp32 valu (no MFMA used; same 157.3 TF peak)",

@@ -326,6 +326,35 @@ def test_c3_2048_tones_decim1000_full_size(cuda_device, gsdr_lib, oracle_mod):
     _full_size_direct(cuda_device, oracle_mod, N=2048, M=1000, nbuf=3, subset=12)
 
 
+def test_pfb_full_size_1024_tones(cuda_device, gsdr_lib, oracle_mod):
+    """TONES at full buffer size: 1024 tones, the client's typical odd nfft (1230 does
+    not divide 1e6: buffer_helper carry every call), oracle on a subset of tones."""
+    import torch
+    from gpu_sdr_amd.source import device_tones, tone_comb
+    rate, L, nfft, avg, N = 200_000_000, 1_000_000, 1230, 4, 1024
+    freq, ampl, phase = tone_comb(N, rate, seed=5)
+    dem = make_pfb(freq, rate, nfft, avg, L)
+    rng = np.random.default_rng(12)
+    pick = np.unique(np.concatenate([[0, 63, 64, N - 1], rng.integers(0, N, size=8)]))
+    ref = oracle_mod.Pfb(freq[pick], rate, nfft, avg, L)
+    np.testing.assert_array_equal(dem.bins()[pick], ref.bins())
+    x = torch.empty(L, dtype=torch.complex64, device=cuda_device)
+    out = torch.empty(dem.out_capacity, dtype=torch.complex64, device=cuda_device)
+    frames = 0
+    for c in range(3):
+        device_tones(x, c * L, rate, freq, ampl, phase, sigma=1e-2, seed=31 + c)
+        n = dem.process(x, out)
+        torch.cuda.synchronize()
+        yr = ref.process(x.cpu().numpy())
+        assert n == N * len(yr)
+        frames += len(yr)
+        y = out[:n].cpu().numpy().reshape(-1, N)
+        err = rel_err_per_tone(y[:, pick], yr)
+        assert err.max() <= TOL, (c, err.max())
+    assert frames == (3 * L - avg * nfft - 1) // nfft + 1
+    dem.close()
+
+
 def test_c3_linearity_all_tones(cuda_device, gsdr_lib):
     """Size-independent property over ALL 2048 tones at full size:
     demod(a + b) == demod(a) + demod(b)."""
