@@ -166,8 +166,11 @@ def run_steps(dem, bufs, out, steps, stream=None):
     return n
 
 
-def time_workload(wl, device, seed, steps, warmup, dist=None, n_tones=None, profile=True):
+def time_workload(wl, device, seed, steps, warmup, dist=None, n_tones=None, profile=True,
+                  ctl_device="same"):
     import torch
+    if ctl_device == "same":
+        ctl_device = device
     dem, bufs, out, N, _ = build_workload(wl, device, seed, n_tones=n_tones)
     stream = torch.cuda.Stream(device)  # the hot path runs on its own (non-null) stream
     torch.cuda.synchronize(device)
@@ -175,14 +178,14 @@ def time_workload(wl, device, seed, steps, warmup, dist=None, n_tones=None, prof
     torch.cuda.synchronize(device)
     if profile:
         dem.profile_enable(True)
-    barrier(dist, device)
+    barrier(dist, ctl_device)
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     run_steps(dem, bufs, out, steps, stream)
     torch.cuda.synchronize(device)
     t1 = time.perf_counter()
-    barrier(dist, device)
-    elapsed = max_over_ranks(dist, t1 - t0, device)
+    barrier(dist, ctl_device)
+    elapsed = max_over_ranks(dist, t1 - t0, ctl_device)
     kn, kms = dem.profile_read() if profile else (0, 0.0)
     kname = dem.kernel_name
     dem.close()
@@ -310,13 +313,18 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (the product path has no CPU fallback)", file=sys.stderr)
         sys.exit(2)
-    device = torch.device("cuda", local_rank)
+    # GSDR_BENCH_ONE_DEVICE=1 / GSDR_BENCH_BACKEND=gloo: rehearsal of the N > 1 path on a
+    # one-GPU box (all ranks on cuda:0, control-plane collectives over gloo on the CPU)
+    one_dev = os.environ.get("GSDR_BENCH_ONE_DEVICE") == "1"
+    backend = os.environ.get("GSDR_BENCH_BACKEND", "nccl")
+    device = torch.device("cuda", 0 if one_dev else local_rank)
     torch.cuda.set_device(device)
-    dist = init_group("nccl") if world > 1 else None
+    dist = init_group(backend) if world > 1 else None
+    ctl_device = device if backend == "nccl" else None   # where barrier/reduce tensors live
 
     wl = WORKLOADS[args.workload]
     seed = stream_seed(rank)
-    r = time_workload(wl, device, seed, args.steps, args.warmup, dist)
+    r = time_workload(wl, device, seed, args.steps, args.warmup, dist, ctl_device=ctl_device)
     samples_total = args.steps * L * world
     value = samples_total / r["elapsed"] / 1e6
     ms_per_step = r["elapsed"] / args.steps * 1e3

@@ -1,0 +1,150 @@
+// rx_link.cpp -- the reference's per-buffer RX loop around the drop-in class.
+//
+// Reproduces TXRX::rx_single_link (ref: cpp/USRP_server_link_threads.cpp:605-702)
+// with the pieces it depends on reduced to their shape:
+//   * a software RX thread that hands over pinned 1 M-sample buffers
+//     (ref: hardware_manager::software_rx_thread, cpp/USRP_hardware_manager.cpp:1331-1395),
+//   * a pool of pinned output buffers of buffer_len*data_mem_mult samples
+//     (ref: preallocator<float2>, headers/USRP_server_memory_management.hpp:103-273,
+//      sized as in cpp/USRP_server_link_threads.cpp:143-150),
+//   * a consumer that stands in for Sync_server::tcp_streamer (drops the packet).
+// The demodulator is include/USRP_demodulator.hpp exactly as the server would
+// compile it.  Reports the PCIe-INCLUSIVE rate of the host-pointer entry
+// (process() is synchronous like the reference: H2D, kernels, D2H, sync).
+//
+//   hipcc -O2 -std=c++17 -Iinclude tools/rx_link.cpp -Lgpu_sdr_amd -lgsdr \
+//         -Wl,-rpath,$PWD/gpu_sdr_amd -lpthread -o /tmp/rx_link
+//   /tmp/rx_link [n_tones=256] [decim=100] [buffers=200]
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
+#include <queue>
+#include <random>
+#include <thread>
+
+#include "USRP_demodulator.hpp"
+
+template <typename T>
+class BlockingQueue {  // stands in for the boost::lockfree queues of the reference
+   public:
+    void push(T v) {
+        { std::lock_guard<std::mutex> l(m_); q_.push(v); }
+        c_.notify_one();
+    }
+    T pop() {
+        std::unique_lock<std::mutex> l(m_);
+        c_.wait(l, [&] { return !q_.empty(); });
+        T v = q_.front();
+        q_.pop();
+        return v;
+    }
+   private:
+    std::mutex m_;
+    std::condition_variable c_;
+    std::queue<T> q_;
+};
+
+int main(int argc, char **argv) {
+    const int n_tones = argc > 1 ? std::atoi(argv[1]) : 256;
+    const int decim = argc > 2 ? std::atoi(argv[2]) : 100;
+    const int n_buffers = argc > 3 ? std::atoi(argv[3]) : 200;
+    const size_t L = 1000000;  // DEFAULT_BUFFER_LEN, ref: headers/USRP_server_settings.hpp:102
+    const int rate = 200000000;
+
+    param p;
+    p.mode = RX;
+    p.rate = rate;
+    p.buffer_len = L;
+    p.decim = decim;
+    p.pf_average = 4;
+    p.fft_tones = 0;
+    p.samples = (size_t)n_buffers * L;
+    std::mt19937 rng(20251004);
+    std::uniform_int_distribution<int> fd(-rate / 2 + 1, rate / 2 - 1);
+    for (int k = 0; k < n_tones; ++k) {
+        p.freq.push_back(fd(rng));  // scripts/get_noise.py:91
+        p.wave_type.push_back(DIRECT);
+    }
+    p.data_mem_mult = (size_t)std::max(std::ceil(n_tones / std::max((double)decim, 1.0)), 1.0);  // USRP_files.py:683-684
+
+    RX_buffer_demodulator::device_index() = 0;
+    RX_buffer_demodulator *demodulator = new RX_buffer_demodulator(&p);  // link_threads.cpp:121
+
+    // pinned pools (preallocator<float2> uses cudaMallocHost)
+    const int pool = 8;
+    const size_t out_len = L * std::max<size_t>(p.data_mem_mult, 1);
+    std::vector<float2 *> in_pool(pool), out_pool(pool);
+    for (int i = 0; i < pool; ++i) {
+        if (hipHostMalloc((void **)&in_pool[i], L * sizeof(float2)) != hipSuccess ||
+            hipHostMalloc((void **)&out_pool[i], out_len * sizeof(float2)) != hipSuccess) {
+            std::fprintf(stderr, "pinned allocation failed\n");
+            return 1;
+        }
+        std::normal_distribution<float> g(0.f, 0.1f);
+        for (size_t j = 0; j < L; ++j) in_pool[i][j] = float2{g(rng), g(rng)};
+    }
+
+    BlockingQueue<RX_wrapper> rx_queue, stream_queue;
+    BlockingQueue<float2 *> in_free, out_free;
+    for (int i = 0; i < pool; ++i) { in_free.push(in_pool[i]); out_free.push(out_pool[i]); }
+
+    // software RX thread: "receives" a buffer (already in pinned memory) and queues it
+    std::thread rx_thread([&] {
+        for (int k = 0; k < n_buffers; ++k) {
+            RX_wrapper w{};
+            w.buffer = in_free.pop();
+            w.usrp_number = 0;
+            w.front_end_code = 'B';  // RX on front-end A is tagged 'B', hardware_manager.cpp:1413-1418
+            w.packet_number = k;
+            w.length = (int)L;
+            w.errors = 0;
+            rx_queue.push(w);
+        }
+    });
+    // streamer stand-in: recycles the output buffer
+    std::atomic<long long> streamed{0};
+    std::thread tx_thread([&] {
+        for (int k = 0; k < n_buffers; ++k) {
+            RX_wrapper w = stream_queue.pop();
+            streamed += w.length;
+            out_free.push(w.buffer);
+        }
+    });
+
+    // ---- rx_single_link, link_threads.cpp:647-690 ----
+    size_t recv_samples = 0;
+    double worst_ms = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    while (recv_samples < p.samples) {
+        RX_wrapper rx_buffer = rx_queue.pop();
+        rx_buffer.channels = (int)demodulator->parameters->wave_type.size();  // :657
+        recv_samples += rx_buffer.length;                                      // :660
+        float2 *output_buffer = out_free.pop();                                // :663
+        const auto a = std::chrono::steady_clock::now();
+        rx_buffer.length = demodulator->process(&rx_buffer.buffer, &output_buffer);  // :666
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
+        if (ms > worst_ms) worst_ms = ms;
+        in_free.push(rx_buffer.buffer);                                        // :669
+        rx_buffer.buffer = output_buffer;                                      // :672
+        stream_queue.push(rx_buffer);                                          // :676
+    }
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    rx_thread.join();
+    tx_thread.join();
+    demodulator->close();
+
+    const double msps = (double)recv_samples / sec / 1e6;
+    std::printf("{\"harness\": \"rx_single_link\", \"tones\": %d, \"decim\": %d, \"buffers\": %d, "
+                "\"msamples_per_s_pcie_inclusive\": %.1f, \"ms_per_buffer\": %.3f, \"worst_ms\": %.3f, "
+                "\"realtime_factor_200Msps\": %.2f, \"streamed_samples\": %lld}\n",
+                n_tones, decim, n_buffers, msps, sec / n_buffers * 1e3, worst_ms, msps / 200.0,
+                streamed.load());
+    for (int i = 0; i < pool; ++i) { (void)hipHostFree(in_pool[i]); (void)hipHostFree(out_pool[i]); }
+    return 0;
+}
