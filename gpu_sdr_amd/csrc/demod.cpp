@@ -53,6 +53,15 @@ struct gsdr_demod {
 
     // host-pointer entry staging
     float2 *d_in = nullptr, *d_out = nullptr;
+    // pipelined host-pointer entry (gsdr_demod_submit / _wait)
+    struct Slot {
+        float2 *d_in = nullptr, *d_out = nullptr;
+        gsdr_c64 *out_host = nullptr;
+        hipEvent_t up = nullptr, done = nullptr, down = nullptr;
+        int n = 0;
+    } slot[GSDR_PIPELINE_DEPTH];
+    hipStream_t s_up = nullptr, s_down = nullptr;
+    int pipe_head = 0, pipe_count = 0;   // oldest outstanding slot, number outstanding
 
     // ---- DDC (DIRECT / TONES) ----
     int F = 0, K = 16, M = 0, Npad = 0, TW = 0, R = 0;
@@ -698,10 +707,73 @@ int gsdr_demod_process(gsdr_demod *h, const gsdr_c64 *in_host, gsdr_c64 *out_hos
     return ret;
 }
 
+int gsdr_demod_submit(gsdr_demod *h, const gsdr_c64 *in_host, gsdr_c64 *out_host) {
+    if (!h) return -1;
+    if (!in_host || !out_host) {
+        h->err = "null buffer";
+        return -1;
+    }
+    if (h->pipe_count >= GSDR_PIPELINE_DEPTH) {
+        h->err = "pipeline full: call gsdr_demod_wait() first";
+        return -1;
+    }
+    if (h->device >= 0) HIPCHK(h, hipSetDevice(h->device));
+    if (!h->s_up) {
+        HIPCHK(h, hipStreamCreateWithFlags(&h->s_up, hipStreamNonBlocking));
+        HIPCHK(h, hipStreamCreateWithFlags(&h->s_down, hipStreamNonBlocking));
+        for (auto &sl : h->slot) {
+            HIPCHK(h, dev_alloc(&sl.d_in, (size_t)h->L));
+            HIPCHK(h, dev_alloc(&sl.d_out, (size_t)h->capacity));
+            HIPCHK(h, hipEventCreateWithFlags(&sl.up, hipEventDisableTiming));
+            HIPCHK(h, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+            HIPCHK(h, hipEventCreateWithFlags(&sl.down, hipEventDisableTiming));
+        }
+    }
+    auto &sl = h->slot[(h->pipe_head + h->pipe_count) % GSDR_PIPELINE_DEPTH];
+    // the slot is free: its previous download was waited for in gsdr_demod_wait()
+    HIPCHK(h, hipMemcpyAsync(sl.d_in, in_host, (size_t)h->L * sizeof(float2), hipMemcpyHostToDevice, h->s_up));
+    HIPCHK(h, hipEventRecord(sl.up, h->s_up));
+    HIPCHK(h, hipStreamWaitEvent(h->stream, sl.up, 0));
+    const int n = gsdr_demod_process_device(h, reinterpret_cast<gsdr_c64 *>(sl.d_in),
+                                            reinterpret_cast<gsdr_c64 *>(sl.d_out), h->stream);
+    if (n < 0) return -1;
+    HIPCHK(h, hipEventRecord(sl.done, h->stream));
+    HIPCHK(h, hipStreamWaitEvent(h->s_down, sl.done, 0));
+    if (n > 0)
+        HIPCHK(h, hipMemcpyAsync(out_host, sl.d_out, (size_t)n * sizeof(float2), hipMemcpyDeviceToHost, h->s_down));
+    HIPCHK(h, hipEventRecord(sl.down, h->s_down));
+    sl.out_host = out_host;
+    sl.n = n;
+    h->pipe_count++;
+    return 0;
+}
+
+int gsdr_demod_wait(gsdr_demod *h) {
+    if (!h) return -1;
+    if (h->pipe_count == 0) return -2;
+    if (h->device >= 0) HIPCHK(h, hipSetDevice(h->device));
+    auto &sl = h->slot[h->pipe_head];
+    HIPCHK(h, hipEventSynchronize(sl.down));
+    h->pipe_head = (h->pipe_head + 1) % GSDR_PIPELINE_DEPTH;
+    h->pipe_count--;
+    return sl.n;
+}
+
 void gsdr_demod_close(gsdr_demod *h) {
     if (!h) return;
     if (h->device >= 0) (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->s_up) (void)hipStreamSynchronize(h->s_up);
+    if (h->s_down) (void)hipStreamSynchronize(h->s_down);
+    for (auto &sl : h->slot) {
+        if (sl.d_in) (void)hipFree(sl.d_in);
+        if (sl.d_out) (void)hipFree(sl.d_out);
+        if (sl.up) (void)hipEventDestroy(sl.up);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+        if (sl.down) (void)hipEventDestroy(sl.down);
+    }
+    if (h->s_up) (void)hipStreamDestroy(h->s_up);
+    if (h->s_down) (void)hipStreamDestroy(h->s_down);
     for (auto &e : h->ev_pool) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);

@@ -217,6 +217,25 @@ class RX_buffer_demodulator:
             raise GsdrError(self._L.gsdr_last_error(self._h).decode())
         return n
 
+    def submit(self, in_buffer: np.ndarray, out_buffer: np.ndarray) -> None:
+        """Pipelined host-pointer entry (gsdr_demod_submit): returns at once; the
+        buffers (ideally pinned) must stay alive until the matching wait()."""
+        if in_buffer.dtype != np.complex64 or out_buffer.dtype != np.complex64:
+            raise TypeError("buffers must be complex64 (float2)")
+        if in_buffer.size < self.parameters.buffer_len or out_buffer.size < self.out_capacity:
+            raise ValueError("buffer too small")
+        if self._L.gsdr_demod_submit(self._h, in_buffer.ctypes.data, out_buffer.ctypes.data) != 0:
+            raise GsdrError(self._L.gsdr_last_error(self._h).decode())
+
+    def wait(self) -> int:
+        """Valid length of the oldest submitted buffer (gsdr_demod_wait)."""
+        n = self._L.gsdr_demod_wait(self._h)
+        if n == -2:
+            raise GsdrError("nothing outstanding")
+        if n < 0:
+            raise GsdrError(self._L.gsdr_last_error(self._h).decode())
+        return n
+
     def close(self) -> None:
         if getattr(self, "_h", None):
             self._L.gsdr_demod_close(self._h)

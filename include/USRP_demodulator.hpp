@@ -146,6 +146,18 @@ class RX_buffer_demodulator {
                                          reinterpret_cast<gsdr_c64*>(out_dev), hip_stream);
     }
 
+    //! pipelined variant of process() (extension, see gsdr_demod_submit in gsdr.h):
+    //! submit up to GSDR_PIPELINE_DEPTH pinned buffers, then wait() for the oldest
+    bool submit(float2** in, float2** out) {
+        return gsdr_demod_submit(handle_, reinterpret_cast<const gsdr_c64*>(*in),
+                                 reinterpret_cast<gsdr_c64*>(*out)) == 0;
+    }
+    int wait() {
+        const int n = gsdr_demod_wait(handle_);
+        if (n == -1) std::fprintf(stderr, "ERROR: demodulator: %s\n", gsdr_last_error(handle_));
+        return n < 0 ? 0 : n;
+    }
+
     //! ref: USRP_demodulator.hpp:33
     void close() {
         if (handle_) gsdr_demod_close(handle_);

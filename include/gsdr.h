@@ -84,6 +84,21 @@ int gsdr_demod_process(gsdr_demod *h, const gsdr_c64 *in_host, gsdr_c64 *out_hos
 int gsdr_demod_process_device(gsdr_demod *h, const gsdr_c64 *in_dev,
                               gsdr_c64 *out_dev, void *hip_stream);
 
+/* Pipelined host-pointer entry (an extension: the reference's process() is
+ * synchronous and serialises H2D, compute and D2H of successive buffers, ref:
+ * cpp/USRP_demodulator.cpp:393,462,555).  gsdr_demod_submit() enqueues the
+ * upload on a copy stream, the kernels on the compute stream and the download
+ * on a third stream, linked by events, and returns at once; up to
+ * GSDR_PIPELINE_DEPTH buffers may be outstanding.  gsdr_demod_wait() blocks
+ * until the OLDEST outstanding buffer is complete in its out_host and returns
+ * its valid length (-1: device error, -2: nothing outstanding).  in_host and
+ * out_host must stay valid until that wait returns and should be pinned
+ * (hipHostMalloc), otherwise the copies degrade to synchronous ones.
+ * Do not mix with gsdr_demod_process() while buffers are outstanding. */
+#define GSDR_PIPELINE_DEPTH 3
+int gsdr_demod_submit(gsdr_demod *h, const gsdr_c64 *in_host, gsdr_c64 *out_host);
+int gsdr_demod_wait(gsdr_demod *h);
+
 /* ref: RX_buffer_demodulator::close, cpp/USRP_demodulator.cpp:333 (+ :466-698).
  * Frees every device allocation and the stream, then the handle itself. */
 void gsdr_demod_close(gsdr_demod *h);

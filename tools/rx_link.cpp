@@ -14,7 +14,9 @@
 //
 //   hipcc -O2 -std=c++17 -Iinclude tools/rx_link.cpp -Lgpu_sdr_amd -lgsdr \
 //         -Wl,-rpath,$PWD/gpu_sdr_amd -lpthread -o /tmp/rx_link
-//   /tmp/rx_link [n_tones=256] [decim=100] [buffers=200]
+//   /tmp/rx_link [n_tones=256] [decim=100] [buffers=200] [pipe]
+// With "pipe" the loop uses the pipelined submit()/wait() pair (upload, kernels
+// and download of successive buffers overlap) instead of the synchronous process().
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -26,6 +28,7 @@
 #include <mutex>
 #include <queue>
 #include <random>
+#include <string>
 #include <thread>
 
 #include "USRP_demodulator.hpp"
@@ -54,6 +57,7 @@ int main(int argc, char **argv) {
     const int n_tones = argc > 1 ? std::atoi(argv[1]) : 256;
     const int decim = argc > 2 ? std::atoi(argv[2]) : 100;
     const int n_buffers = argc > 3 ? std::atoi(argv[3]) : 200;
+    const bool pipelined = argc > 4 && std::string(argv[4]) == "pipe";
     const size_t L = 1000000;  // DEFAULT_BUFFER_LEN, ref: headers/USRP_server_settings.hpp:102
     const int rate = 200000000;
 
@@ -121,29 +125,45 @@ int main(int argc, char **argv) {
     size_t recv_samples = 0;
     double worst_ms = 0;
     const auto t0 = std::chrono::steady_clock::now();
+    std::queue<std::pair<RX_wrapper, float2 *>> in_flight;  // pipelined mode: submitted, not yet waited for
+    auto retire = [&] {
+        auto pr = in_flight.front();
+        in_flight.pop();
+        pr.first.length = demodulator->wait();
+        in_free.push(pr.first.buffer);
+        pr.first.buffer = pr.second;
+        stream_queue.push(pr.first);
+    };
     while (recv_samples < p.samples) {
         RX_wrapper rx_buffer = rx_queue.pop();
         rx_buffer.channels = (int)demodulator->parameters->wave_type.size();  // :657
         recv_samples += rx_buffer.length;                                      // :660
         float2 *output_buffer = out_free.pop();                                // :663
         const auto a = std::chrono::steady_clock::now();
-        rx_buffer.length = demodulator->process(&rx_buffer.buffer, &output_buffer);  // :666
+        if (pipelined) {
+            if ((int)in_flight.size() == GSDR_PIPELINE_DEPTH) retire();
+            demodulator->submit(&rx_buffer.buffer, &output_buffer);
+            in_flight.push({rx_buffer, output_buffer});
+        } else {
+            rx_buffer.length = demodulator->process(&rx_buffer.buffer, &output_buffer);  // :666
+            in_free.push(rx_buffer.buffer);                                    // :669
+            rx_buffer.buffer = output_buffer;                                  // :672
+            stream_queue.push(rx_buffer);                                      // :676
+        }
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
         if (ms > worst_ms) worst_ms = ms;
-        in_free.push(rx_buffer.buffer);                                        // :669
-        rx_buffer.buffer = output_buffer;                                      // :672
-        stream_queue.push(rx_buffer);                                          // :676
     }
+    while (!in_flight.empty()) retire();
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     rx_thread.join();
     tx_thread.join();
     demodulator->close();
 
     const double msps = (double)recv_samples / sec / 1e6;
-    std::printf("{\"harness\": \"rx_single_link\", \"tones\": %d, \"decim\": %d, \"buffers\": %d, "
+    std::printf("{\"harness\": \"rx_single_link%s\", \"tones\": %d, \"decim\": %d, \"buffers\": %d, "
                 "\"msamples_per_s_pcie_inclusive\": %.1f, \"ms_per_buffer\": %.3f, \"worst_ms\": %.3f, "
                 "\"realtime_factor_200Msps\": %.2f, \"streamed_samples\": %lld}\n",
-                n_tones, decim, n_buffers, msps, sec / n_buffers * 1e3, worst_ms, msps / 200.0,
+                pipelined ? " (submit/wait)" : "", n_tones, decim, n_buffers, msps, sec / n_buffers * 1e3, worst_ms, msps / 200.0,
                 streamed.load());
     for (int i = 0; i < pool; ++i) { (void)hipHostFree(in_pool[i]); (void)hipHostFree(out_pool[i]); }
     return 0;
