@@ -46,6 +46,7 @@ struct gsdr_demod {
     std::string err;
 
     int N = 0;              // channels = wave_type.size()
+    int ddc_channels = 0;   // tones the DDC kernels run (== N except NOISE: fft_tones)
     long long L = 0;        // buffer_len
     long long decim = 0;
     long long capacity = 0; // max samples process() can return
@@ -155,7 +156,7 @@ int build_nco_tables(gsdr_demod *h, const std::vector<long long> &tone, unsigned
     std::vector<double2> wk(Npad), wrem(Npad);
     for (int n = 0; n < Npad; ++n) {
         unsigned long long fm = 0;
-        if (n < h->N) {
+        if (n < h->ddc_channels) {
             long long r = tone[n] % (long long)rate;
             if (r < 0) r += rate;
             fm = (unsigned long long)r;
@@ -234,7 +235,8 @@ int setup_ddc_common(gsdr_demod *h, int F, int M, unsigned rate,
     h->F = F;
     h->M = M;
     h->nco_rate = rate;
-    h->Npad = ((h->N + 63) / 64) * 64;
+    if (h->ddc_channels <= 0) h->ddc_channels = h->N;
+    h->Npad = ((h->ddc_channels + 63) / 64) * 64;
     h->TW = h->Npad / 64;
     // ddc_flat_kernel (packed math, pipelined scalar loads) covers F <= 4;
     // ddc_kernel is the generic fallback (and GSDR_DDC_PIPE=0 forces it, for A/B runs)
@@ -378,7 +380,7 @@ int enqueue_pfb(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t st) {
         a.tails = h->d_tails;
         a.carry_in = nullptr;   // frames never reach back before raw_input[0]
         a.carry_out = nullptr;
-        a.sh.N = h->N;
+        a.sh.N = h->ddc_channels;
         a.sh.Npad = h->Npad;
         a.sh.TW = h->TW;
         a.sh.rate = h->nco_rate;
@@ -407,7 +409,7 @@ int enqueue_pfb(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t st) {
         HIPCHK(h, hipMemcpyAsync(h->d_raw, tmp, (size_t)h->bh.spare_samples * sizeof(float2),
                                  hipMemcpyDeviceToDevice, st));
     }
-    const int ret = h->N * cb;           // :546
+    const int ret = h->ddc_channels * cb;  // :546 (TONES), copy_size :638 (NOISE)
     gsdr_buffer_helper_update(&h->bh);   // :552
     return ret;
 }
@@ -567,26 +569,39 @@ gsdr_demod *gsdr_demod_create(const gsdr_param_c *p) {
             }
             break;
         }
-        case GSDR_TONES: {  // ref: :121-175, :702-768
+        case GSDR_TONES:    // ref: :121-175, :702-768
+        case GSDR_NOISE: {  // ref: :264-313 (full spectrum: every FFT bin is a channel)
+            const bool noise = (last == GSDR_NOISE);
             if (!need(p->rate > 0, "rate must be positive")) return nullptr;
             if (!need(p->fft_tones >= 1, "fft_tones must be >= 1")) return nullptr;
-            if (!need(p->pf_average >= 1 && p->pf_average <= kMaxF, "pf_average must be in [1,8] for TONES")) return nullptr;
-            if (!need(p->n_freq >= h->N && p->freq, "TONES needs one frequency per wave_type entry")) return nullptr;
+            if (!need(p->pf_average >= 1 && p->pf_average <= kMaxF, "pf_average must be in [1,8] for TONES/NOISE")) return nullptr;
+            if (!need(noise || (p->n_freq >= h->N && p->freq), "TONES needs one frequency per wave_type entry")) return nullptr;
             if (!need(h->decim <= 0,
-                      "TONES with decim > 0 is not supported: the reference path is broken "
-                      "(ref: kernels.cu:779, USRP_demodulator.cpp:172,516)")) return nullptr;
+                      "TONES/NOISE with decim > 0 is not supported: the reference path is broken "
+                      "(ref: kernels.cu:718-719,747,779, USRP_demodulator.cpp:172,516)")) return nullptr;
             if (!need((long long)p->fft_tones * p->pf_average <= 0x7fffffffLL, "fft_tones*pf_average overflows")) return nullptr;
+            // NOISE evaluates all nfft bins with the DDC kernel (O(nfft) per sample, no FFT):
+            // fine for the bin counts the client uses for spectra, refused beyond
+            if (!need(!noise || p->fft_tones <= 16384,
+                      "NOISE supports fft_tones <= 16384 in this build (direct evaluation of every bin)")) return nullptr;
             h->nfft = p->fft_tones;
             const int F = (int)p->pf_average;
-            h->fcut = (float)(1. / (2 * h->nfft));                     // :131
+            h->fcut = (float)(1. / (2 * h->nfft));                     // :131, :274
             h->window.resize((size_t)h->nfft * F);
-            gsdr_make_sinc_window(h->nfft * F, h->fcut, h->window.data());  // :134
+            gsdr_make_sinc_window(h->nfft * F, h->fcut, h->window.data());  // :134, :277
             h->batching = gsdr_pfb_batching(h->L, h->nfft, F);         // :706
-            h->bins.resize(h->N);
-            gsdr_pfb_tone_bins(p->rate, h->nfft, p->freq, h->N, h->bins.data());  // :722-733
-            std::vector<long long> tone(h->N);
-            for (int u = 0; u < h->N; ++u) tone[u] = h->bins[u] < 0 ? 0 : h->bins[u];
-            gsdr_buffer_helper_init(&h->bh, h->nfft, (int)h->L, F, h->N);  // :159
+            const int n_ch = noise ? h->nfft : h->N;                   // channels of the DDC launch
+            h->bins.resize(n_ch);
+            if (noise) {
+                for (int u = 0; u < n_ch; ++u) h->bins[u] = u;         // process_pfb_spec keeps every bin
+            } else {
+                gsdr_pfb_tone_bins(p->rate, h->nfft, p->freq, h->N, h->bins.data());  // :722-733
+            }
+            std::vector<long long> tone(n_ch);
+            for (int u = 0; u < n_ch; ++u) tone[u] = h->bins[u] < 0 ? 0 : h->bins[u];
+            // buffer_helper(n_tones, buffer_len, average, n_eff_tones): :159 / :301
+            gsdr_buffer_helper_init(&h->bh, h->nfft, (int)h->L, F, n_ch);
+            h->ddc_channels = n_ch;
             rc = setup_ddc_common(h, F, h->nfft, (unsigned)h->nfft, tone,
                                   (int)(h->L / h->nfft) + F + 6);
             h->kernel_name = h->pipe ? gsdr::ddc_flat_kernel_name() : gsdr::ddc_kernel_name();
@@ -599,7 +614,7 @@ gsdr_demod *gsdr_demod_create(const gsdr_param_c *p) {
                     rc = -1;
                 }
             }
-            h->capacity = (long long)h->N * h->batching;               // :147
+            h->capacity = (long long)n_ch * h->batching;               // :147 / :288
             break;
         }
         case GSDR_CHIRP: {  // ref: :177-262
@@ -643,9 +658,6 @@ gsdr_demod *gsdr_demod_create(const gsdr_param_c *p) {
             h->capacity = h->L;
             h->kernel_name = "memcpy";
             break;
-        case GSDR_NOISE:
-            fail_create(h, "NOISE (full-spectrum PFB) demodulation is not implemented in this build");
-            return nullptr;
         default:  // ref: :322-325
             fail_create(h, "Void demodulation operation has not been implemented yet!");
             return nullptr;
@@ -670,7 +682,8 @@ int gsdr_demod_process_device(gsdr_demod *h, const gsdr_c64 *in_dev, gsdr_c64 *o
     float2 *out = reinterpret_cast<float2 *>(out_dev);
     switch (h->mode) {
         case GSDR_DIRECT: return enqueue_direct(h, in, out, st);
-        case GSDR_TONES: return enqueue_pfb(h, in, out, st);
+        case GSDR_TONES:
+        case GSDR_NOISE: return enqueue_pfb(h, in, out, st);
         case GSDR_CHIRP: return enqueue_chirp(h, in, out, st);
         case GSDR_NODSP:  // ref: process_nodsp :335-339
             HIPCHK(h, hipMemcpyAsync(out, in, (size_t)h->L * sizeof(float2),

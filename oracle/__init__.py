@@ -76,6 +76,8 @@ def lib():
     L.oracle_direct_taps.restype = fp
     L.oracle_pfb_create.argtypes = [ip, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long]
     L.oracle_pfb_create.restype = vp
+    L.oracle_noise_create.argtypes = [C.c_int, C.c_long, C.c_long]
+    L.oracle_noise_create.restype = vp
     L.oracle_pfb_process.argtypes = [vp, vp, vp]
     L.oracle_pfb_process.restype = C.c_long
     L.oracle_pfb_destroy.argtypes = [vp]
@@ -247,6 +249,15 @@ class Pfb:
             self._h = None
 
     __del__ = close
+
+
+class Noise(Pfb):
+    """NOISE demodulator, decim == 0: full spectra (cpp/USRP_demodulator.cpp:264-313, 568-649)."""
+
+    def __init__(self, fft_tones, pf_average, buffer_len):
+        self.n_tones, self.nfft, self.avg, self.L = int(fft_tones), int(fft_tones), int(pf_average), int(buffer_len)
+        self.batching = pfb_batching(buffer_len, fft_tones, pf_average)
+        self._h = lib().oracle_noise_create(fft_tones, pf_average, buffer_len)
 
 
 def chirp_demod(cp: ChirpParam, last_index: int, x) -> np.ndarray:

@@ -341,6 +341,28 @@ oracle_pfb *oracle_pfb_create(const int *freq, int n_tones, int rate,
     return p;
 }
 
+/* NOISE, decim == 0: cpp/USRP_demodulator.cpp:264-313 (ctor) and :568-649
+ * (process_pfb_spec).  Same polyphase filter + forward FFT as TONES, but every
+ * FFT bin is kept: n_eff_tones = fft_tones in buffer_helper (:301) and the
+ * returned length is copy_size = fft_tones * current_batch (:638). */
+oracle_pfb *oracle_noise_create(int fft_tones, long pf_average, long buffer_len) {
+    oracle_pfb *p = (oracle_pfb *)calloc(1, sizeof(*p));
+    p->n_tones = fft_tones;
+    p->rate = fft_tones;
+    p->nfft = fft_tones;
+    p->avg = pf_average;
+    p->L = buffer_len;
+    p->bins = (int *)malloc(sizeof(int) * (size_t)fft_tones);
+    for (int u = 0; u < fft_tones; u++) p->bins[u] = u;
+    p->batching = oracle_pfb_batching(buffer_len, fft_tones, pf_average);
+    p->window = (float *)malloc(sizeof(float) * (size_t)(fft_tones * pf_average));
+    float fcut = (float)(1. / (2 * fft_tones));                 /* :274 */
+    oracle_make_sinc_window((int)(fft_tones * pf_average), fcut, p->window); /* :277 */
+    p->raw = (oc64 *)calloc((size_t)fft_tones * (size_t)p->batching, sizeof(oc64));
+    oracle_buffer_helper_init(&p->bh, fft_tones, (int)buffer_len, (int)pf_average, fft_tones);
+    return p;
+}
+
 const int *oracle_pfb_bins(const oracle_pfb *p) { return p->bins; }
 
 void oracle_pfb_destroy(oracle_pfb *p) {

@@ -88,6 +88,9 @@ typedef struct oracle_pfb oracle_pfb;
 /* cpp/USRP_demodulator.cpp:121-175,702-768 */
 oracle_pfb *oracle_pfb_create(const int *freq, int n_tones, int rate,
                               int fft_tones, long pf_average, long buffer_len);
+/* NOISE (full spectrum, decim==0): cpp/USRP_demodulator.cpp:264-313, 568-649;
+ * processed and destroyed with oracle_pfb_process / oracle_pfb_destroy */
+oracle_pfb *oracle_noise_create(int fft_tones, long pf_average, long buffer_len);
 /* cpp/USRP_demodulator.cpp:486-565 (decim==0 branch) */
 long oracle_pfb_process(oracle_pfb *p, const oc64 *in, oc64 *out);
 void oracle_pfb_destroy(oracle_pfb *p);

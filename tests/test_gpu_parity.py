@@ -230,6 +230,28 @@ def test_pfb_parity(cuda_device, gsdr_lib, oracle_mod, case):
     dem.close()
 
 
+@pytest.mark.parametrize("nfft,avg,L,nbuf", [(16, 3, 200, 4), (100, 4, 50_000, 3), (1000, 4, 50_123, 3),
+                                            (64, 1, 4096, 2)])
+def test_noise_full_spectrum_parity(cuda_device, gsdr_lib, oracle_mod, nfft, avg, L, nbuf):
+    """NOISE, decim == 0 (ref: process_pfb_spec): every FFT bin, [frame][bin]."""
+    import gpu_sdr_amd as g
+    rng = np.random.default_rng(4000 + nfft)
+    p = g.param(mode="RX", rate=1_000_000, buffer_len=L, decim=0, pf_average=avg, fft_tones=nfft,
+                freq=[0], wave_type=[g.w_type.NOISE])
+    dem = g.RX_buffer_demodulator(p, device_index=0)
+    ref = oracle_mod.Noise(nfft, avg, L)
+    assert dem.channels == 1                       # rx_single_link reports wave_type.size() channels
+    assert dem.out_capacity == nfft * ref.batching
+    for c in range(nbuf):
+        x = crandn(rng, L)
+        y = (run_host if c % 2 else run_device)(dem, x, *(() if c % 2 else (cuda_device,)))
+        yr = ref.process(x)
+        assert y.size == yr.size
+        if yr.size:
+            assert rel_err_per_tone(y.reshape(-1, nfft), yr).max() <= TOL
+    dem.close()
+
+
 # ---------------------------------------------------------------------------
 # CHIRP (VNA)
 # ---------------------------------------------------------------------------
@@ -482,8 +504,10 @@ def test_unsupported_requests_fail_loudly(cuda_device, gsdr_lib):
         g.RX_buffer_demodulator(g.param(decim=7, wave_type=[g.w_type.DIRECT] * 2, **base), device_index=0)
     with pytest.raises(g.GsdrError, match="pf_average"):
         g.RX_buffer_demodulator(g.param(decim=10, pf_average=9, wave_type=[g.w_type.DIRECT] * 2, **base), device_index=0)
-    with pytest.raises(g.GsdrError, match="NOISE"):
-        g.RX_buffer_demodulator(g.param(fft_tones=10, wave_type=[g.w_type.NOISE], **base), device_index=0)
+    with pytest.raises(g.GsdrError, match="fft_tones <= 16384"):
+        g.RX_buffer_demodulator(g.param(fft_tones=20000, wave_type=[g.w_type.NOISE], **base), device_index=0)
+    with pytest.raises(g.GsdrError, match="not supported"):
+        g.RX_buffer_demodulator(g.param(decim=2, fft_tones=10, wave_type=[g.w_type.NOISE], **base), device_index=0)
     with pytest.raises(g.GsdrError, match="Void demodulation"):
         g.RX_buffer_demodulator(g.param(wave_type=[g.w_type.RAMP], **base), device_index=0)
 
