@@ -12,9 +12,13 @@ struct DdcShape {
     int M;                     // samples per block (decimation / nfft)
     int nblk;                  // input blocks in this launch
     int nch;                   // chunks the blocks are split into
+    int cbase, crem;           // nblk / nch and nblk % nch (chunk_begin(), no device division)
     int g_off;                 // first output kept; out row = G - g_off
     unsigned rate;             // NCO modulus (sample rate, or nfft for TONES)
     unsigned long long idx0;   // NCO index of x[0] (mod rate)
+    unsigned long long rate_magic;  // floor((2^64-1)/rate), Barrett reduction mod rate
+    double inv_rate;           // 1.0 / rate
+    unsigned m_mod_rate;       // M mod rate
     long long total;           // mix_kernel only: number of samples
     long long xlast;           // ddc_flat_kernel: x[0 .. xlast+4) is readable
     int prefetch;              // ddc_flat_kernel: LDS-DMA L2 prefetch of the IQ stream on/off

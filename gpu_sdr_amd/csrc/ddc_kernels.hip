@@ -33,18 +33,10 @@
 //     reference's FIR::_dout carry, cpp/fir.cu:64-69).
 #include <hip/hip_runtime.h>
 
+#include "ddc_device.h"
 #include "ddc_kernels.h"
 
 namespace gsdr {
-
-// exp(-2*pi*i * ph/rate) for an exact integer phase 0 <= ph < rate.
-__device__ __forceinline__ void exact_phasor(unsigned long long ph, unsigned rate,
-                                             double &re, double &im) {
-    double s, c;
-    sincospi(2.0 * ((double)ph / (double)rate), &s, &c);
-    re = c;
-    im = -s;
-}
 
 template <int F, int K>
 __global__ __launch_bounds__(256) void ddc_kernel(
@@ -74,15 +66,16 @@ __global__ __launch_bounds__(256) void ddc_kernel(
     const double2 WK = wk[n];
     const double2 WR = wrem[n];
 
-    const int b0 = (int)(((long long)chunk * sh.nblk) / sh.nch);
-    const int b1 = (int)(((long long)(chunk + 1) * sh.nblk) / sh.nch);
+    const int b0 = chunk_begin(chunk, sh);
+    const int b1 = chunk_begin(chunk + 1, sh);
 
     // exact NCO phase at the first sample of the chunk
     // ref: kernels.cu:66-69  ii=(j+idx)%rate; phase=(tf*ii)%rate
-    const unsigned long long s0 = (sh.idx0 + (unsigned long long)b0 * (unsigned)M) % sh.rate;
-    const unsigned long long ph = ((unsigned long long)fmod[n] * s0) % sh.rate;
+    const unsigned long long s0 =
+        mod_rate(sh.idx0 + (unsigned long long)b0 * sh.m_mod_rate, sh.rate, sh.rate_magic);
+    const unsigned long long ph = mod_rate((unsigned long long)fmod[n] * s0, sh.rate, sh.rate_magic);
     double Pr, Pi;
-    exact_phasor(ph, sh.rate, Pr, Pi);
+    exact_phasor(ph, sh.inv_rate, Pr, Pi);
 
     float2 A[F];  // A[k]: partial sum of output G = b + k while block b is processed
 #pragma unroll
@@ -185,8 +178,8 @@ __global__ void ddc_fixup(float2 *__restrict__ out, const float2 *__restrict__ t
     } else {
         src = tails[((size_t)c * Fm1 + k) * sh.Npad + n];
     }
-    const int b0 = (int)(((long long)c * sh.nblk) / sh.nch);
-    const int b1 = (int)(((long long)(c + 1) * sh.nblk) / sh.nch);
+    const int b0 = chunk_begin(c, sh);
+    const int b1 = chunk_begin(c + 1, sh);
     const int G = b0 + k;
     if (G < b1) {
         if (G >= sh.g_off && n < sh.N) {
@@ -226,13 +219,14 @@ __global__ __launch_bounds__(256) void mix_kernel(
     const double2 WK = wk[n];
 
     // chunks are whole multiples of K samples (sh.M = samples per unit = K)
-    const long long u0 = ((long long)chunk * sh.nblk) / sh.nch;
-    const long long u1 = ((long long)(chunk + 1) * sh.nblk) / sh.nch;
+    const long long u0 = chunk_begin(chunk, sh);
+    const long long u1 = chunk_begin(chunk + 1, sh);
     const long long total = sh.total;  // L
-    const unsigned long long s0 = (sh.idx0 + (unsigned long long)u0 * K) % sh.rate;
-    const unsigned long long ph = ((unsigned long long)fmod[n] * s0) % sh.rate;
+    const unsigned long long s0 =
+        mod_rate(sh.idx0 + (unsigned long long)u0 * sh.m_mod_rate, sh.rate, sh.rate_magic);
+    const unsigned long long ph = mod_rate((unsigned long long)fmod[n] * s0, sh.rate, sh.rate_magic);
     double Pr, Pi;
-    exact_phasor(ph, sh.rate, Pr, Pi);
+    exact_phasor(ph, sh.inv_rate, Pr, Pi);
 
     for (long long u = u0; u < u1; ++u) {
         const long long base = u * K;

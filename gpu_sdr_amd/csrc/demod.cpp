@@ -283,6 +283,15 @@ int setup_ddc_common(gsdr_demod *h, int F, int M, unsigned rate,
     return 0;
 }
 
+// fields of DdcShape the kernels derive nothing from on the device
+void finish_shape(DdcShape &sh) {
+    sh.cbase = sh.nblk / (sh.nch > 0 ? sh.nch : 1);
+    sh.crem = sh.nblk % (sh.nch > 0 ? sh.nch : 1);
+    sh.rate_magic = 0xffffffffffffffffULL / sh.rate;
+    sh.inv_rate = 1.0 / (double)sh.rate;
+    sh.m_mod_rate = (unsigned)sh.M % sh.rate;
+}
+
 int record_begin(gsdr_demod *h, hipStream_t st, hipEvent_t *stop) {
     *stop = nullptr;
     if (!h->prof || h->ev_used >= (size_t)kMaxEvents) return 0;
@@ -340,6 +349,7 @@ int enqueue_direct(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t st)
             a.x = h->d_stage;
             a.sh.xlast = h->L + h->pad - 4;
         }
+        finish_shape(a.sh);
         if (record_begin(h, st, &stop)) return -1;
         HIPCHK(h, gsdr::launch_ddc(h->F, h->K, a, st, stop));
         h->parity ^= 1;
@@ -352,6 +362,7 @@ int enqueue_direct(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t st)
         if (nch < 1) nch = 1;
         if (nch > a.sh.nblk) nch = a.sh.nblk;
         a.sh.nch = (int)nch;
+        finish_shape(a.sh);
         if (record_begin(h, st, &stop)) return -1;
         HIPCHK(h, gsdr::launch_mix(h->K, a, st));
         if (stop) HIPCHK(h, hipEventRecord(stop, st));
@@ -395,6 +406,7 @@ int enqueue_pfb(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t st) {
         int nch = pick_chunks(h, a.sh.nblk);
         if (nch > h->nch_max) nch = h->nch_max;
         a.sh.nch = nch;
+        finish_shape(a.sh);
         hipEvent_t stop = nullptr;
         if (record_begin(h, st, &stop)) return -1;
         HIPCHK(h, gsdr::launch_ddc(h->F, h->K, a, st, stop));
