@@ -34,6 +34,7 @@ struct DdcLaunch {
     const unsigned *fmod;
     float2 *out;
     float2 *tails;
+    int tails_nch;          // chunk slots `tails` was allocated for (launch_ddc refuses more)
     const float2 *carry_in;
     float2 *carry_out;
     DdcShape sh;

@@ -277,6 +277,10 @@ static hipError_t launch_ddc_k(int F, const DdcLaunch &a, hipStream_t st) {
 }
 
 hipError_t launch_ddc(int F, int K, const DdcLaunch &a, hipStream_t st, hipEvent_t stop) {
+    // shapes are checked on the host: a kernel that writes past `tails` faults the GPU
+    if (a.sh.nch < 1 || a.sh.nblk < 1 || a.sh.TW < 1 || (F > 1 && a.sh.nch > a.tails_nch) ||
+        (F > 1 && a.sh.nch > 1 && a.sh.nblk / a.sh.nch < F - 1))
+        return hipErrorInvalidValue;
     hipError_t e;
     if (a.pipe) e = launch_ddc_flat_main(F, K, a, st);
     else if (K == 16) e = launch_ddc_k<16>(F, a, st);

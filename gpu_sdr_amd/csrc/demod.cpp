@@ -70,8 +70,10 @@ struct gsdr_demod {
     unsigned long long idx = 0;        // DIRECT_current_index (ref :88, :437-440)
     int target_waves = 4096;           // resident waves the DDC grid is sized for
     int simds = 1024;                  // SIMDs of the device (4 per CU)
-    int nch_max = 1;
+    int nch_max = 1;                   // chunks of the DIRECT launch (fixed nblk)
+    int tails_nch = 0;                 // chunk count the tails buffer was sized for (0: not yet)
     int nch_force = 0;                 // GSDR_DDC_NCH: experiment override
+    double waves_ratio = 1.3;          // grid waves / resident waves (autotuned in create)
     unsigned lds_bytes = 0;            // GSDR_DDC_LDS: dummy LDS per workgroup (occupancy cap)
     int prefetch = 1;                  // GSDR_DDC_PREFETCH: L2 prefetch of the IQ stream
     std::vector<float> window;         // taps (DIRECT) / PFB window / VNA profile, real part
@@ -196,23 +198,12 @@ int upload_taps_transposed(gsdr_demod *h) {
     return 0;
 }
 
-// Number of chunks the blocks of one launch are cut into (one wave per
-// chunk x 64 tones).  Measured on MI355X (gpurun_out/sweep2/3, C2 and C3): wave
-// run times spread widely, so a grid ~1.3x larger than what is resident at once
-// -- the hardware dispatcher hands the surplus workgroups to whichever CU frees
-// up first -- beats an exactly-resident grid, and chunks of EQUAL length beat
-// both.  So: aim at 1.3 x resident waves, and within +-25 % of that prefer the
-// chunk count that splits the blocks most evenly.
-int pick_chunks(const gsdr_demod *h, int nblk) {
-    if (nblk <= 0) return 1;
-    const int TW = h->TW > 0 ? h->TW : 1;
-    const long long cap = (h->F > 1) ? nblk / (h->F - 1) : nblk;  // every chunk >= F-1 blocks
-    if (cap < 1) return 1;
-    if (h->nch_force > 0) return (int)(h->nch_force < cap ? h->nch_force : cap);
-    long long want = (long long)(1.3 * h->target_waves) / TW;
+// Chunk count closest to `want` (within +-20 %) that splits nblk blocks most
+// evenly: the launch ends with its longest chunk.
+long long balanced_near(long long want, int nblk, long long cap) {
     if (want < 1) want = 1;
     if (want > cap) want = cap;
-    long long lo = want - want / 4, hi = want + want / 4;
+    long long lo = want - want / 5, hi = want + want / 5;
     if (lo < 1) lo = 1;
     if (hi > cap) hi = cap;
     long long best_nch = want;
@@ -220,14 +211,33 @@ int pick_chunks(const gsdr_demod *h, int nblk) {
     for (long long nch = lo; nch <= hi; ++nch) {
         const long long longest = (nblk + nch - 1) / nch;
         const double balance = ((double)nblk / (double)nch) / (double)longest;
-        const double dist = std::fabs((double)(nch - want)) / (double)want;
-        const double score = balance - 0.02 * dist;
+        const double score = balance - 0.05 * std::fabs((double)(nch - want)) / (double)want;
         if (score > best) {
             best = score;
             best_nch = nch;
         }
     }
-    return (int)best_nch;
+    return best_nch;
+}
+
+// Number of chunks the blocks of one launch are cut into (one wave per chunk x
+// 64 tones).  `h->waves_ratio` = grid waves / resident waves; 1.3 by default
+// (measured on C3: a grid 1.3x what is resident -- the dispatcher hands the
+// surplus workgroups to whichever CU frees up first -- beats an exactly
+// resident one by 9 %), replaced by the autotuned value when create() could
+// time the candidates (profiles/r01_chunk_sweeps.log shows why a fixed rule is
+// not enough: C2 is best at 0.8, C3 at 1.3-1.7).
+int pick_chunks(const gsdr_demod *h, int nblk) {
+    if (nblk <= 0) return 1;
+    const int TW = h->TW > 0 ? h->TW : 1;
+    const long long cap = (h->F > 1) ? nblk / (h->F - 1) : nblk;  // every chunk >= F-1 blocks
+    if (cap < 1) return 1;
+    long long nch = h->nch_force > 0
+                        ? (h->nch_force < cap ? h->nch_force : cap)
+                        : balanced_near((long long)(h->waves_ratio * h->target_waves) / TW, nblk, cap);
+    // never more chunks than the tails buffer has slots for (0 = not allocated yet)
+    if (h->tails_nch > 0 && nch > h->tails_nch) nch = h->tails_nch;
+    return (int)(nch < 1 ? 1 : nch);
 }
 
 int setup_ddc_common(gsdr_demod *h, int F, int M, unsigned rate,
@@ -274,10 +284,21 @@ int setup_ddc_common(gsdr_demod *h, int F, int M, unsigned rate,
     h->nch_force = env_int("GSDR_DDC_NCH", 0);
     h->lds_bytes = (unsigned)env_int("GSDR_DDC_LDS", 0);
     h->prefetch = env_int("GSDR_DDC_PREFETCH", 1);
+    // the tails buffer must hold the largest chunk count any launch may pick:
+    // largest autotune ratio (1.7) x the +20 % window of balanced_near(), or the
+    // forced count, but never more than one chunk per F-1 blocks
+    {
+        const long long cap = (F > 1) ? max_nblk / (F - 1) : max_nblk;
+        long long worst = (long long)(1.7 * 1.2 * h->target_waves) / h->TW + 2;
+        if (h->nch_force > worst) worst = h->nch_force;
+        if (worst > cap) worst = cap;
+        h->tails_nch = (int)(worst < 1 ? 1 : worst);
+    }
+    h->waves_ratio = 1.3;
     h->nch_max = pick_chunks(h, max_nblk);
     if (build_nco_tables(h, tone, rate)) return -1;
     if (upload_taps_transposed(h)) return -1;
-    const size_t tail_elems = (size_t)(h->nch_max + 1) * (size_t)(F > 1 ? F - 1 : 1) * h->Npad;
+    const size_t tail_elems = (size_t)(h->tails_nch + 1) * (size_t)(F > 1 ? F - 1 : 1) * h->Npad;
     HIPCHK(h, dev_alloc(&h->d_tails, tail_elems));
     HIPCHK(h, hipMemset(h->d_tails, 0, tail_elems * sizeof(float2)));
     return 0;
@@ -311,6 +332,85 @@ int record_begin(gsdr_demod *h, hipStream_t st, hipEvent_t *stop) {
 // per-mode enqueue
 // ---------------------------------------------------------------------------
 
+// Grid size of the DDC launch, measured instead of guessed: times the real
+// launch (ddc kernel + fixup) on scratch buffers for a few grid/resident ratios
+// and keeps the fastest.  Runs once in create(); GSDR_DDC_AUTOTUNE=0 keeps 1.3.
+int autotune_chunks(gsdr_demod *h, int nblk) {
+    h->waves_ratio = 1.3;
+    if (!h->pipe || h->nch_force > 0 || env_int("GSDR_DDC_AUTOTUNE", 1) == 0 || nblk < 1) {
+        h->nch_max = pick_chunks(h, nblk);
+        return 0;
+    }
+    const size_t n_in = (size_t)nblk * h->M + h->pad + 8;
+    const size_t n_out = (size_t)nblk * h->ddc_channels;
+    float2 *x = nullptr, *y = nullptr;
+    HIPCHK(h, dev_alloc(&x, n_in));
+    if (dev_alloc(&y, n_out) != hipSuccess) {
+        (void)hipFree(x);
+        h->err = "autotune scratch allocation failed";
+        return -1;
+    }
+    (void)hipMemset(x, 0x3c, n_in * sizeof(float2));  // 0.0115f everywhere: finite, non-zero
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    const double cand[] = {0.8, 1.0, 1.3, 1.7};
+    double best_ms = 1e30, best_ratio = 1.3;
+    int rc = 0;
+    for (double r : cand) {
+        h->waves_ratio = r;
+        DdcLaunch a{};
+        a.x = x;
+        a.taps_t = h->d_taps_t;
+        a.taps_p = h->d_taps_p;
+        a.btab = h->d_btab;
+        a.wk = h->d_wk;
+        a.wrem = h->d_wrem;
+        a.fmod = h->d_fmod;
+        a.out = y;
+        a.tails = h->d_tails;
+        a.tails_nch = h->tails_nch;
+        a.pipe = true;
+        a.lds_bytes = h->lds_bytes;
+        a.sh.N = h->ddc_channels;
+        a.sh.Npad = h->Npad;
+        a.sh.TW = h->TW;
+        a.sh.rate = h->nco_rate;
+        a.sh.M = h->M;
+        a.sh.nblk = nblk;
+        a.sh.nch = pick_chunks(h, nblk);
+        a.sh.xlast = (long long)nblk * h->M + h->pad - 4;
+        a.sh.prefetch = h->prefetch;
+        finish_shape(a.sh);
+        float ms = 0.f;
+        for (int it = 0; it < 4 && !rc; ++it) {  // first iteration warms up
+            if (it == 1) rc |= hipEventRecord(e0, h->stream) != hipSuccess;
+            rc |= gsdr::launch_ddc(h->F, h->K, a, h->stream, nullptr) != hipSuccess;
+        }
+        rc |= hipEventRecord(e1, h->stream) != hipSuccess;
+        rc |= hipEventSynchronize(e1) != hipSuccess;
+        if (rc || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) {
+            rc = 1;
+            break;
+        }
+        if (ms < best_ms) {
+            best_ms = ms;
+            best_ratio = r;
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(x);
+    (void)hipFree(y);
+    if (rc) {
+        h->err = "autotune launch failed";
+        return -1;
+    }
+    h->waves_ratio = best_ratio;
+    h->nch_max = pick_chunks(h, nblk);
+    return 0;
+}
+
 // ref: process_direct, cpp/USRP_demodulator.cpp:400-464
 int enqueue_direct(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t st) {
     DdcLaunch a{};
@@ -335,6 +435,7 @@ int enqueue_direct(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t st)
     hipEvent_t stop = nullptr;
     if (h->decim > 0) {
         a.tails = h->d_tails;
+        a.tails_nch = h->tails_nch;
         a.carry_in = h->d_carry[h->parity];
         a.carry_out = h->d_carry[h->parity ^ 1];
         a.sh.M = h->M;
@@ -389,6 +490,7 @@ int enqueue_pfb(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t st) {
         a.fmod = h->d_fmod;
         a.out = out;
         a.tails = h->d_tails;
+        a.tails_nch = h->tails_nch;
         a.carry_in = nullptr;   // frames never reach back before raw_input[0]
         a.carry_out = nullptr;
         a.sh.N = h->ddc_channels;
@@ -403,8 +505,7 @@ int enqueue_pfb(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t st) {
         a.sh.prefetch = h->prefetch;
         a.sh.xlast = (long long)a.sh.nblk * h->M + h->pad - 4;  // d_raw is twice the window
         a.sh.g_off = h->F - 1;      // DDC output G <-> frame r = G-(F-1)
-        int nch = pick_chunks(h, a.sh.nblk);
-        if (nch > h->nch_max) nch = h->nch_max;
+        const int nch = pick_chunks(h, a.sh.nblk);
         a.sh.nch = nch;
         finish_shape(a.sh);
         hipEvent_t stop = nullptr;
@@ -569,6 +670,7 @@ gsdr_demod *gsdr_demod_create(const gsdr_param_c *p) {
                         }
                     }
                 }
+                if (!rc) rc = autotune_chunks(h, (int)(h->L / M));
                 h->capacity = (long long)h->N * (h->L / M);
             } else {
                 // undecimated: only the NCO tables are needed
@@ -626,6 +728,7 @@ gsdr_demod *gsdr_demod_create(const gsdr_param_c *p) {
                     rc = -1;
                 }
             }
+            if (!rc) rc = autotune_chunks(h, (int)(h->L / h->nfft) + F - 1);
             h->capacity = (long long)n_ch * h->batching;               // :147 / :288
             break;
         }
