@@ -1,0 +1,80 @@
+"""Host-side mirror of the reference's TX_buffer_generator, used as the
+synthetic in-memory IQ source for loop-back runs (the reference's --sw_loop
+memcpys TX buffers into the RX queue, cpp/USRP_hardware_manager.cpp:1071-1123,
+1331-1395).
+
+  * TONES: the reference builds a length-`rate` buffer by placing ampl[k] at bin
+    freq[k] (rate + freq[k] for negative tones) of an UNNORMALISED inverse FFT
+    (tone_gen, cpp/kernels.cu:589-684) and serves successive buffer_len slices
+    of it, wrapping at `rate` (get_from_tones, cpp/USRP_buffer_generator.cpp:226-229).
+    That buffer is the closed form  x[n] = sum_k ampl[k] exp(+2 pi i freq[k] n / rate),
+    n taken mod rate, which the HIP source kernel evaluates directly.
+  * CHIRP: chirp_gen law (cpp/kernels.cu:335-372) scaled by ampl[0], the running
+    index wrapping at num_steps*length (get_from_chirp, :208-221).
+Other wave types raise like the reference exits (:37-52).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+from .demodulator import GsdrError, chirp_derive, param, w_type
+from .source import device_chirp, device_tones
+
+
+class TX_buffer_generator:
+    """class TX_buffer_generator, headers/USRP_buffer_generator.hpp.
+
+    ``get(out)`` fills a torch complex64 CUDA tensor of ``buffer_len`` samples
+    with the next TX buffer; ``close()`` is a no-op kept for symmetry."""
+
+    def __init__(self, init_parameters: param):
+        p = self.parameters = init_parameters
+        self.buffer_len = int(p.buffer_len)
+        if not p.wave_type:
+            raise GsdrError("TX buffer generation needs at least one wave_type")
+        last = p.wave_type[0]
+        if sum(1 for w in p.wave_type if w == w_type.CHIRP) > 1:
+            raise GsdrError("Multiple chirp TX buffer generation has been requested. "
+                            "This feature is not implemented yet.")
+        if any(w != last for w in p.wave_type):
+            raise GsdrError("Mixed TX buffer generation has been requested. "
+                            "This feature is not implemented yet.")
+        self.mode = w_type(last)
+        if self.mode in (w_type.NODSP, w_type.SWONLY):
+            raise GsdrError("NODSP CASE NOT IMPLEMENTED.")
+        if self.mode in (w_type.RAMP, w_type.DIRECT):
+            raise GsdrError("RAMP CASE NOT IMPLEMENTED.")
+        if self.mode == w_type.NOISE:
+            raise GsdrError("NOISE TX generation is empty in the reference (get_from_noise)")
+        if self.mode == w_type.TONES:
+            n = len(p.wave_type)
+            if len(p.freq) < n or len(p.ampl) < n:
+                raise GsdrError("TONES needs freq[] and ampl[] for every wave_type entry")
+            self._freq = np.asarray(p.freq[:n], dtype=np.int32)
+            self._ampl = np.asarray(p.ampl[:n], dtype=np.float32)
+            self._phase = np.zeros(n, dtype=np.float32)
+            # TONES_buffer_len: rate, or the multiple of it that holds one buffer (:60-75)
+            self._period = int(p.rate) * max(1, -(-self.buffer_len // int(p.rate)))
+            self._last = 0            # TONES_last_sample
+        else:  # CHIRP
+            cp = chirp_derive(p.rate, p.freq[0], p.chirp_f[0], p.swipe_s[0], p.chirp_t[0])
+            # the TX side also resets num_steps when a step would be shorter than one
+            # sample (cpp/USRP_buffer_generator.cpp:111-115); the RX side does not
+            if np.float32(p.chirp_t[0]) * np.float32(p.rate) / np.float32(cp.num_steps) < 1:
+                cp.num_steps = int(np.float32(p.chirp_t[0]) * np.float32(p.rate))
+            self._cp = cp
+            self._scale = float(p.ampl[0]) if p.ampl else 1.0
+            self._last = 0            # last_index
+
+    def get(self, out_tensor, stream=None) -> None:
+        if self.mode == w_type.TONES:
+            device_tones(out_tensor, self._last, int(self.parameters.rate), self._freq, self._ampl,
+                         self._phase, sigma=0.0, stream=stream)
+            self._last = (self._last + self.buffer_len) % self._period
+        else:
+            device_chirp(out_tensor, self._last, self._cp, scale=self._scale, stream=stream)
+            self._last = (self._last + self.buffer_len) % (self._cp.num_steps * self._cp.length)
+
+    def close(self) -> None:
+        pass

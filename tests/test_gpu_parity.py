@@ -483,6 +483,59 @@ def test_pipelined_submit_wait_equals_process(cuda_device, gsdr_lib):
         b.close()
 
 
+def test_sw_loop_tx_tones_into_rx_direct(cuda_device, gsdr_lib):
+    """The reference's --sw_loop chain: TX_buffer_generator(TONES) buffers fed
+    straight to RX_buffer_demodulator(DIRECT).  TX is the unnormalised IFFT comb
+    (amplitude a_k per tone), so every demodulated channel settles on a_k + 0j
+    and stays there across the buffer wrap of the length-`rate` TX table."""
+    import torch
+    import gpu_sdr_amd as g
+    rate, L, M, F = 1_000_000, 100_000, 100, 4
+    freq = [-400_000 + 50_000 * k + 137 for k in range(16)]
+    ampl = [1.0 / 16] * 16                       # pyUSRP/USRP_noise.py:477
+    tx = g.TX_buffer_generator(g.param(mode="TX", rate=rate, buffer_len=L, freq=freq, ampl=ampl,
+                                       wave_type=[g.w_type.TONES] * 16))
+    rx = make_direct(freq, rate, M, F, L)
+    x = torch.empty(L, dtype=torch.complex64, device=cuda_device)
+    out = torch.empty(rx.out_capacity, dtype=torch.complex64, device=cuda_device)
+    for c in range(12):                          # 1.2 s of stream: wraps the TX table once
+        tx.get(x)
+        n = rx.process(x, out)
+        torch.cuda.synchronize()
+        y = out[:n].cpu().numpy().reshape(-1, 16)
+        if c > 0:
+            assert np.abs(y - 1.0 / 16).max() < 2e-4
+    rx.close()
+    tx.close()
+    with pytest.raises(g.GsdrError, match="Mixed TX"):
+        g.TX_buffer_generator(g.param(rate=rate, buffer_len=L, freq=[1, 2], ampl=[1, 1],
+                                      wave_type=[g.w_type.TONES, g.w_type.CHIRP]))
+    with pytest.raises(g.GsdrError, match="NOT IMPLEMENTED"):
+        g.TX_buffer_generator(g.param(rate=rate, buffer_len=L, wave_type=[g.w_type.DIRECT]))
+
+
+def test_sw_loop_tx_chirp_into_rx_chirp(cuda_device, gsdr_lib):
+    """TX chirp generator -> RX chirp demodulator with lock-in: a flat S21 = ampl."""
+    import torch
+    import gpu_sdr_amd as g
+    rate, L = 200_000_000, 1_000_000
+    p = dict(rate=rate, buffer_len=L, freq=[-80_000_000], chirp_f=[80_000_000], swipe_s=[10_000],
+             chirp_t=[0.0075], wave_type=[g.w_type.CHIRP])          # length 150, sweep = 1.5 buffers
+    tx = g.TX_buffer_generator(g.param(mode="TX", ampl=[0.25], **p))
+    rx = g.RX_buffer_demodulator(g.param(mode="RX", decim=1, **p), device_index=0)
+    x = torch.empty(L, dtype=torch.complex64, device=cuda_device)
+    out = torch.empty(rx.out_capacity, dtype=torch.complex64, device=cuda_device)
+    total = 0
+    for c in range(4):
+        tx.get(x)
+        n = rx.process(x, out)
+        torch.cuda.synchronize()
+        total += n
+        np.testing.assert_allclose(out[:n].cpu().numpy(), 0.25 + 0j, rtol=0, atol=2e-6)
+    assert total == (4 * L) // 150
+    rx.close()
+
+
 def test_nodsp_passthrough(cuda_device, gsdr_lib):
     import gpu_sdr_amd as g
     rng = np.random.default_rng(8)
