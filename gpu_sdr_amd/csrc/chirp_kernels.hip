@@ -64,6 +64,11 @@ __device__ __forceinline__ int chirp_index(unsigned long long e, const ChirpShap
     return (int)idx;
 }
 
+// the 32-bit fast kernels cover num_steps, length and period below 2^31 / 2^32
+__host__ __device__ inline bool chirp_fits_32(const ChirpShape &cs) {
+    return cs.period < 0xffffffffull && cs.num_steps < 0x7fffffffull && cs.length < 0x800000ull;
+}
+
 __device__ __forceinline__ float2 demod_one(float2 in, int index) {
     float s, c;
     sincos_index(index, s, c);
@@ -74,7 +79,7 @@ __device__ __forceinline__ float2 demod_one(float2 in, int index) {
     return o;
 }
 
-__global__ __launch_bounds__(256) void chirp_demod_kernel(const float2 *__restrict__ in,
+__global__ __launch_bounds__(256) void chirp_demod_generic_kernel(const float2 *__restrict__ in,
                                                           float2 *__restrict__ out, long long n,
                                                           unsigned long long index0,
                                                           ChirpShape cs) {
@@ -94,7 +99,7 @@ __global__ __launch_bounds__(256) void chirp_demod_kernel(const float2 *__restri
 }
 
 // One wave per output point v (4 per workgroup).
-__global__ __launch_bounds__(256) void chirp_lockin_kernel(
+__global__ __launch_bounds__(256) void chirp_lockin_generic_kernel(
     const float2 *__restrict__ carry, int carry_len, const float2 *__restrict__ in,
     const float *__restrict__ profile, int ppt, int valid, float2 *__restrict__ out,
     unsigned long long index0, ChirpShape cs) {
@@ -123,13 +128,130 @@ __global__ __launch_bounds__(256) void chirp_lockin_kernel(
     if (lane == 0) out[v] = make_float2(sx, sy);
 }
 
+// ---------------------------------------------------------------------------
+// Fast paths (every realistic sweep: num_steps and the period fit 32 bits).
+//
+// Within one frequency step fi the chirp index is LINEAR in the sample:
+//     index(fi*len + r) = K(fi) + r*A(fi)   (mod 2^32)
+//     A = f0 + fi*c,   K = fi*len*A - c*len*q(fi),   q = fi(fi+1)/2
+// and the lock-in windows are aligned to steps (ppt = len*decim and the stream
+// position of every window is a multiple of ppt), so the per-sample 64-bit
+// modulo/divide of the generic kernels reduces to one multiply-add; A and K are
+// wave-uniform in the lock-in kernel.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void step_coeffs(unsigned fi, const ChirpShape &cs, unsigned &A,
+                                            unsigned &K) {
+    const unsigned len = (unsigned)cs.length;
+    const unsigned q = (fi >> 1) * (fi + 1u) + (fi & 1u) * ((fi + 1u) >> 1);
+    A = (unsigned)cs.f0 + fi * cs.chirpness;
+    K = fi * len * A - cs.chirpness * (len * q);
+}
+
+// (index0 + pos) mod period with 32-bit arithmetic (index0 < period < 2^32, pos < 2^32)
+__device__ __forceinline__ unsigned wrap_index(unsigned long long index0, unsigned pos,
+                                               const ChirpShape &cs) {
+    const unsigned per = (unsigned)cs.period;
+    const unsigned long long t = index0 + (unsigned long long)(pos % per);
+    return (unsigned)(t >= per ? t - per : t);
+}
+
+// One wave per output point.  All loads of a 256-sample stretch are issued before
+// any of them is used (one memory round trip per stretch, not one per sample).
+__global__ __launch_bounds__(256) void chirp_lockin_kernel(
+    const float2 *__restrict__ carry, int carry_len, const float2 *__restrict__ in,
+    const float *__restrict__ profile, int ppt, int valid, float2 *__restrict__ out,
+    unsigned long long index0, ChirpShape cs) {
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int v = (int)blockIdx.x * 4 + wid;
+    if (v >= valid) return;
+    const unsigned len = (unsigned)cs.length, steps = (unsigned)cs.num_steps;
+    const unsigned base = (unsigned)v * (unsigned)ppt;  // position in the logical stage [carry | in]
+    const unsigned e0 = wrap_index(index0, base, cs);   // a multiple of len
+    unsigned fi = e0 / len;
+    const int decim = ppt / (int)len;
+    float sx = 0.f, sy = 0.f;
+    for (int d = 0; d < decim; ++d) {
+        unsigned A, K;
+        step_coeffs(fi, cs, A, K);
+        const unsigned seg = base + (unsigned)d * len;
+        const float *w_seg = profile + (size_t)d * len;
+        for (unsigned r0 = 0; r0 < len; r0 += 256) {
+            float w[4];
+            float2 smp[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned r = r0 + (unsigned)(i * 64 + lane);
+                const bool ok = r < len;
+                const unsigned pos = seg + (ok ? r : 0u);
+                w[i] = ok ? w_seg[r] : 0.f;
+                smp[i] = (int)pos < carry_len ? carry[pos] : in[pos - (unsigned)carry_len];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned r = r0 + (unsigned)(i * 64 + lane);
+                const float2 dm = demod_one(smp[i], (int)(K + r * A));
+                sx = fmaf(dm.x, w[i], sx);
+                sy = fmaf(dm.y, w[i], sy);
+            }
+        }
+        fi = fi + 1 == steps ? 0 : fi + 1;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sx += __shfl_xor(sx, off, 64);
+        sy += __shfl_xor(sy, off, 64);
+    }
+    if (lane == 0) out[v] = make_float2(sx, sy);
+}
+
+// Undecimated demodulation: 4 consecutive runs of 64 samples per wave; the step
+// index of a sample is the wave's base step plus a small quotient.
+__global__ __launch_bounds__(256) void chirp_demod_kernel(const float2 *__restrict__ in,
+                                                          float2 *__restrict__ out, long long n,
+                                                          unsigned long long index0,
+                                                          ChirpShape cs) {
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned len = (unsigned)cs.length, steps = (unsigned)cs.num_steps;
+    const float inv_len = 1.0f / (float)len;
+    const long long wave_stride = (long long)gridDim.x * 4 * 256;
+    for (long long o0 = ((long long)blockIdx.x * 4 + wid) * 256; o0 < n; o0 += wave_stride) {
+        const unsigned e_w = wrap_index(index0, (unsigned)o0, cs);
+        const unsigned fi_w = e_w / len, r_w = e_w - fi_w * len;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long long o = o0 + i * 64 + lane;
+            if (o < n) {
+                unsigned r = r_w + (unsigned)(i * 64 + lane);        // < len + 256
+                unsigned qd = (unsigned)((float)r * inv_len);         // r / len, off by at most one
+                unsigned rem = r - qd * len;
+                if ((int)rem < 0) { qd--; rem += len; }
+                if (rem >= len) { qd++; rem -= len; }
+                unsigned fi = fi_w + qd;
+                if (fi >= steps) fi %= steps;
+                unsigned A, K;
+                step_coeffs(fi, cs, A, K);
+                out[o] = demod_one(in[o], (int)(K + rem * A));
+            }
+        }
+    }
+}
+
 hipError_t launch_chirp_demod(const float2 *in, float2 *out, long long n,
                               unsigned long long index0, const ChirpShape &cs, hipStream_t st) {
     if (n <= 0) return hipSuccess;
-    long long blocks = (n + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(chirp_demod_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, out, n,
-                       index0, cs);
+    if (chirp_fits_32(cs)) {
+        long long blocks = (n + 1023) / 1024;  // 256 samples per wave
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        hipLaunchKernelGGL(chirp_demod_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, out, n,
+                           index0, cs);
+    } else {
+        long long blocks = (n + 255) / 256;
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        hipLaunchKernelGGL(chirp_demod_generic_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in,
+                           out, n, index0, cs);
+    }
     return hipGetLastError();
 }
 
@@ -137,8 +259,14 @@ hipError_t launch_chirp_lockin(const float2 *carry, int carry_len, const float2 
                                const float *profile, int ppt, int valid, float2 *out,
                                unsigned long long index0, const ChirpShape &cs, hipStream_t st) {
     if (valid <= 0) return hipSuccess;
-    hipLaunchKernelGGL(chirp_lockin_kernel, dim3((unsigned)((valid + 3) / 4)), dim3(256), 0, st,
-                       carry, carry_len, in, profile, ppt, valid, out, index0, cs);
+    // the fast kernel needs windows made of whole steps that start on a step boundary:
+    // true for every window the demodulator forms (ppt = length*decim, see enqueue_chirp)
+    if (chirp_fits_32(cs) && ppt % (int)cs.length == 0 && index0 % cs.length == 0)
+        hipLaunchKernelGGL(chirp_lockin_kernel, dim3((unsigned)((valid + 3) / 4)), dim3(256), 0, st,
+                           carry, carry_len, in, profile, ppt, valid, out, index0, cs);
+    else
+        hipLaunchKernelGGL(chirp_lockin_generic_kernel, dim3((unsigned)((valid + 3) / 4)), dim3(256),
+                           0, st, carry, carry_len, in, profile, ppt, valid, out, index0, cs);
     return hipGetLastError();
 }
 
