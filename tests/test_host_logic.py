@@ -36,6 +36,18 @@ def test_cpp_shim_header_compiles_with_gxx(tmp_path):
     subprocess.check_call(["g++", "-std=c++11", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)])
 
 
+def test_c_header_is_plain_c(tmp_path):
+    """include/gsdr.h is the FFI boundary: it must compile as C (C99, pedantic),
+    which is what a cgo/JNI/ctypes binding generator would feed on."""
+    src = tmp_path / "t.c"
+    src.write_text('#include "gsdr.h"\n'
+                   "int main(void){ gsdr_param_c p; gsdr_buffer_helper b; gsdr_vna_helper v; gsdr_chirp_param c;\n"
+                   " (void)p; (void)b; (void)v; (void)c; return GSDR_ABI_VERSION == 1 && GSDR_PIPELINE_DEPTH >= 2 ? 0 : 1; }\n")
+    import subprocess
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only",
+                           "-I", os.path.join(ROOT, "include"), str(src)])
+
+
 @pytest.mark.parametrize("length,fc", [(40, 0.0375), (400, 0.75 / 200), (4000, 0.75 / 2000),
                                         (41, 0.0375), (30, 1. / 20), (12, 1. / 6), (1, 0.1), (2, 0.25)])
 def test_sinc_window_bit_exact(gsdr_lib, oracle_mod, length, fc):
