@@ -52,6 +52,20 @@ class VnaHelperC(C.Structure):
         "valid_size", "new0", "total_len", "spare_begin", "ppt", "buffer_len")]
 
 
+class AntennaInfoC(C.Structure):
+    """struct gsdr_antenna_info"""
+    _fields_ = [("mode", C.c_int), ("rf", C.c_double), ("gain", C.c_int), ("bw", C.c_int),
+                ("tuning_mode", C.c_int), ("samples", C.c_longlong), ("delay", C.c_double),
+                ("burst_on", C.c_float), ("burst_off", C.c_float), ("data_mem_mult", C.c_longlong),
+                ("ampl", C.POINTER(C.c_float)), ("n_ampl", C.c_int)]
+
+
+class RxHeaderC(C.Structure):
+    """struct gsdr_rx_header"""
+    _fields_ = [("usrp_number", C.c_int), ("front_end_code", C.c_char), ("packet_number", C.c_int),
+                ("length", C.c_int), ("errors", C.c_int), ("channels", C.c_int)]
+
+
 class ChirpParamC(C.Structure):
     """struct gsdr_chirp_param"""
     _fields_ = [("num_steps", C.c_ulonglong), ("length", C.c_ulonglong),
@@ -88,6 +102,14 @@ SIGNATURES = [
     ("gsdr_pfb_batching", C.c_int, [C.c_longlong, C.c_int, C.c_longlong]),
     ("gsdr_chirp_derive", None, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                  C.POINTER(ChirpParamC)]),
+    ("gsdr_command_parse", _vp, [C.c_char_p, C.c_int]),
+    ("gsdr_command_free", None, [_vp]),
+    ("gsdr_command_error", C.c_char_p, []),
+    ("gsdr_command_device", C.c_int, [_vp]),
+    ("gsdr_command_antenna", C.c_int, [_vp, C.c_int, C.POINTER(ParamC), C.POINTER(AntennaInfoC)]),
+    ("gsdr_server_reply", C.c_int, [C.c_int, C.c_char_p, C.c_char_p, C.c_int]),
+    ("gsdr_format_async_header", None, [C.c_int, C.POINTER(C.c_ubyte)]),
+    ("gsdr_format_rx_header", None, [C.POINTER(RxHeaderC), C.POINTER(C.c_ubyte)]),
     ("gsdr_source_tones", C.c_int, [_vp, C.c_longlong, C.c_longlong, C.c_int, _ip, _fp, _fp,
                                     C.c_int, C.c_float, C.c_ulonglong, _vp]),
     ("gsdr_source_chirp", C.c_int, [_vp, C.c_longlong, C.c_ulonglong,

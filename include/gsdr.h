@@ -172,6 +172,53 @@ typedef struct gsdr_chirp_param {
 void gsdr_chirp_derive(int rate, int freq0, int chirp_f, int swipe_s,
                        float chirp_t, gsdr_chirp_param *cp);
 
+/* ---- the pyUSRP command surface (host only) ------------------------------
+ * One JSON command per measurement arrives on the async socket, framed by an
+ * 8-byte header; results leave on the data socket as 21-byte header + complex64
+ * payload (wire formats: SURVEY.md section 9). */
+typedef struct gsdr_command gsdr_command;   /* a parsed and checked usrp_param */
+
+/* ref: string2param (cpp/USRP_JSON_interpreter.cpp:19-257) followed by chk_param
+ * (:268-439): every key of A_TXRX, B_TXRX, A_RX2, B_RX2 is mandatory; buffer_len
+ * 0 or outside [50000, 6000000] -> 1000000; PFB modes force pf_average >= 1 and
+ * fft_tones >= 2; |freq|, |chirp_f| <= rate for TONES/CHIRP.  NULL = the command
+ * must be nack'ed; gsdr_command_error() says why. */
+gsdr_command *gsdr_command_parse(const char *json, int len);
+void gsdr_command_free(gsdr_command *c);
+const char *gsdr_command_error(void);
+int gsdr_command_device(const gsdr_command *c);            /* usrp_param::usrp_number */
+
+/* the fields of `struct param` that gsdr_param_c does not carry
+ * (ref: headers/USRP_server_settings.hpp:130-167) */
+typedef struct gsdr_antenna_info {
+    int mode;                 /* ant_mode: 0 TX, 1 RX, 2 OFF */
+    double rf;                /* param::tone                     */
+    int gain, bw, tuning_mode;
+    long long samples;
+    double delay;
+    float burst_on, burst_off;
+    long long data_mem_mult;
+    const float *ampl;
+    int n_ampl;
+} gsdr_antenna_info;
+/* antenna: 0 A_TXRX, 1 B_TXRX, 2 A_RX2, 3 B_RX2 (usrp_param member order).  The
+ * pointers inside *p and *info stay valid until gsdr_command_free(). */
+int gsdr_command_antenna(const gsdr_command *c, int antenna, gsdr_param_c *p, gsdr_antenna_info *info);
+
+/* ref: server_ack / server_nack (cpp/USRP_JSON_interpreter.cpp:441-457), in the
+ * layout boost::property_tree::write_json produces.  Returns the text length. */
+int gsdr_server_reply(int is_ack, const char *payload, char *buf, int cap);
+/* ref: Async_server::format_header, cpp/USRP_server_network.cpp:497-501: {0, len} */
+void gsdr_format_async_header(int message_len, unsigned char out[8]);
+/* ref: RX_wrapper without its pointer (headers/USRP_server_settings.hpp:216-224)
+ * and Sync_server::format_net_buffer (cpp/USRP_server_network.cpp:164-191) */
+typedef struct gsdr_rx_header {
+    int usrp_number;
+    char front_end_code;
+    int packet_number, length, errors, channels;
+} gsdr_rx_header;
+void gsdr_format_rx_header(const gsdr_rx_header *h, unsigned char out[21]);
+
 /* ---- synthetic in-memory IQ source (replaces the UHD hardware manager for
  * benchmarking; shaped after software_rx_thread, ref:
  * cpp/USRP_hardware_manager.cpp:1331-1395) ------------------------------- */
