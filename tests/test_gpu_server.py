@@ -1,0 +1,120 @@
+"""End to end over TCP (row f2): a client that frames its command exactly like
+pyUSRP (Encode_async_message, USRP_connections.py:484-498; packets decoded with
+header_type, USRP_low_level.py:63-70) talks to tools/gsdr_server.cpp running the
+software loop-back on the GPU."""
+import json
+import os
+import socket
+import struct
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+HEADER = np.dtype([("usrp_number", np.int32), ("front_end_code", "|S1"), ("packet_number", np.int32),
+                   ("length", np.int32), ("errors", np.int32), ("channels", np.int32)])
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def recv_all(sock, n):
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = sock.recv(n - len(buf))
+        if not chunk:
+            raise ConnectionError("socket closed")
+        buf += chunk
+    return bytes(buf)
+
+
+def recv_async(sock):
+    zero, n = struct.unpack("II", recv_all(sock, 8))
+    assert zero == 0
+    return json.loads(recv_all(sock, n))
+
+
+def connect(port, tries=100):
+    for _ in range(tries):
+        try:
+            return socket.create_connection(("127.0.0.1", port), timeout=60)
+        except OSError:
+            time.sleep(0.1)
+    raise ConnectionError(port)
+
+
+@pytest.fixture()
+def server(cuda_device, gsdr_lib):
+    exe = os.path.join(ROOT, "gpu_sdr_amd", "gsdr_server")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "gpu_sdr_amd", "csrc")])
+    pa, pd = free_port(), free_port()
+    proc = subprocess.Popen([exe, "--async", str(pa), "--data", str(pd), "--device", "0", "--sw_loop"])
+    data = connect(pd)
+    asyn = connect(pa)
+    yield asyn, data
+    asyn.close()
+    data.close()
+    try:
+        proc.wait(timeout=20)
+    except subprocess.TimeoutExpired:
+        proc.kill()
+
+
+def send_command(asyn, cmd):
+    payload = json.dumps(cmd).encode()
+    asyn.sendall(struct.pack("I", 0) + struct.pack("I", len(payload)) + payload)
+
+
+def test_get_noise_direct_over_tcp(server):
+    from make_commands import get_noise_direct
+    asyn, data = server
+    tones = [-40000000 + 5000000 * k + 1234 for k in range(16)]
+    cmd = get_noise_direct(tones, 100000000, 0.03, 100, 300e6)          # 3 buffers of 1 M samples
+    send_command(asyn, cmd)
+    assert recv_async(asyn) == {"type": "ack", "payload": "Message received"}
+    rows = []
+    for k in range(3):
+        h = np.frombuffer(recv_all(data, 21), dtype=HEADER)[0]
+        assert (h["usrp_number"], h["front_end_code"], h["packet_number"], h["errors"], h["channels"]) == \
+            (0, b"B", k, 0, 16)
+        assert h["length"] == 16 * 10000
+        z = np.frombuffer(recv_all(data, int(h["length"]) * 8), dtype=np.complex64)
+        rows.append(z.reshape(-1, 16))                                    # Packets_to_file: (samples, channels)
+    reply = recv_async(asyn)
+    assert reply["type"] == "ack" and "EOM" in reply["payload"]
+    y = np.concatenate(rows)[8:]
+    # TX comb with ampl 1/16 per tone, looped back and demodulated: every channel sits at 1/16
+    assert np.abs(y - 1.0 / 16).max() < 2e-4
+    # a malformed command is nack'ed and the server keeps serving
+    bad = dict(cmd)
+    bad = {k: v for k, v in cmd.items() if k != "B_RX2"}
+    send_command(asyn, bad)
+    assert recv_async(asyn) == {"type": "nack", "payload": "Cannot convert JSON to params"}
+
+
+def test_single_vna_over_tcp(server):
+    from make_commands import single_vna
+    asyn, data = server
+    cmd = single_vna(-80000000, 80000000, 0.01, 10000, 200000000, 300e6, amplitude=0.5)   # 2 buffers, ppt 200
+    send_command(asyn, cmd)
+    assert recv_async(asyn)["type"] == "ack"
+    got = []
+    for k in range(2):
+        h = np.frombuffer(recv_all(data, 21), dtype=HEADER)[0]
+        assert h["channels"] == 1 and h["front_end_code"] == b"B" and h["packet_number"] == k
+        assert h["length"] == 5000
+        got.append(np.frombuffer(recv_all(data, int(h["length"]) * 8), dtype=np.complex64))
+    assert "EOM" in recv_async(asyn)["payload"]
+    np.testing.assert_allclose(np.concatenate(got), 0.5 + 0j, rtol=0, atol=3e-6)     # flat S21 of the loop-back
