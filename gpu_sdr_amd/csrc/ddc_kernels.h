@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <vector>
+
 namespace gsdr {
 
 // Shape of one DDC launch; passed to the kernels by value.
@@ -54,6 +56,60 @@ hipError_t launch_ddc_flat_main(int F, int PK, const DdcLaunch &a, hipStream_t s
 const char *ddc_kernel_name();
 const char *ddc_flat_kernel_name();
 const char *mix_kernel_name();
+
+// ---- DDC on the matrix cores (ddc_mfma.hip) --------------------------------
+struct MfmaShape {
+    int N;                     // tones
+    int NT32;                  // 32-tone tiles the tables hold (= ntg * TT)
+    int ntg;                   // tone groups (one wave each) = ceil(ceil(N/32) / TT)
+    int ntq;                   // workgroups per row tile = ceil(ntg / 4)
+    int ngt;                   // row tiles = ceil(nout / 32)
+    int M;                     // samples per block
+    int MF;                    // window length in samples (M * F)
+    int nk8;                   // MFMA k-steps of 8 samples = ceil(MF / 8)
+    int nout;                  // output rows of this launch
+    int woff;                  // row o's window starts at sample (o + woff) * M
+    int carry_len;             // samples of history in front of sample 0 (in `head`)
+    long long tail0;           // first sample held by `tail`
+    long long nx;              // x[0 .. nx) is readable
+    unsigned rate;             // NCO modulus
+    unsigned long long rate_magic;
+    double inv_rate;
+    unsigned m_mod_rate;
+    unsigned idx_base;         // NCO index of sample woff*M (mod rate)
+    int slot_cur, slot_prev;   // absmax slots of this and the previous buffer
+    float unscale;             // power of two the taps were divided by
+};
+
+struct MfmaLaunch {
+    const float2 *x;
+    const float2 *head;        // row tile 0 reads here: sample s at head[s + carry_len]
+    const float2 *tail;        // last row tile reads here: sample s at tail[s - tail0], zeros past nx
+    const float *taps;         // [nk8*8 + 8] scaled, zero padded
+    const uint4 *bfrag;        // phasor-table operand images, see mfma_build_tables
+    const float2 *ptab;        // [ceil(nk8/KS)][NT32*32]  w_n^(hi*PK)
+    const float2 *dtab;        // [32][NT32*32]            w_n^(row*M)
+    const unsigned *fmod;      // [NT32*32]
+    const unsigned *maxbits;   // [3] absmax slots
+    float2 *out;
+    MfmaShape sh;
+};
+
+struct MfmaPlan {
+    int TT, PK;                // tone tiles per wave (1, 2), phasor block (16, 32)
+    int ntg, nk8, MF, M;
+    unsigned rate;
+};
+
+void mfma_build_tables(const MfmaPlan &pl, const std::vector<unsigned> &fmod_in, const float *window,
+                       std::vector<uint4> &bfrag, std::vector<float2> &ptab,
+                       std::vector<float2> &dtab, std::vector<float> &taps,
+                       std::vector<unsigned> &fmod, float &unscale);
+hipError_t launch_absmax(const float2 *x, long long n, unsigned *slots, int cur, int next,
+                         float2 *head_cur, long long head_n, float2 *head_next, int carry_len,
+                         float2 *tail, long long tail0, hipStream_t st);
+hipError_t launch_ddc_mfma(int TT, int PK, int W, int sgb, const MfmaLaunch &a, hipStream_t st);
+const char *ddc_mfma_kernel_name();
 
 // ---- chirp ---------------------------------------------------------------
 struct ChirpShape {

@@ -1,0 +1,453 @@
+// ddc_mfma.hip -- the DDC on the matrix cores (gfx950, v_mfma_f32_32x32x16_f16).
+//
+// Same arithmetic as ddc_kernel / ddc_flat_kernel,
+//     y[n,o] = sum_{t < M*F} h[t] * x[(o+woff)*M + t] * w_n^(idx + (o+woff)*M + t),
+// (ref: direct_demodulator_integer + FIR, cpp/kernels.cu:45-86, cpp/fir.cu:48-61;
+//  TONES: polyphase_filter + FFT bin, cpp/kernels.cu:718-779)
+// arranged as a GEMM whose one operand never changes.  With t = hi*PK + lo,
+//     y[n,o] = rot[n,o] * sum_hi P_n[hi] * ( sum_lo b[o,hi,lo] * B_n[lo] ),
+//     b = S*h[t]*x[...] (tone independent),  B_n[lo] = w_n^lo,  P_n[hi] = w_n^(hi*PK),
+//     rot[n,o] = w_n^(idx + (o+woff)*M) / S.
+// The inner sum is a [32 rows o] x [2*PK reals] x [32 tones] real matrix product
+// per 32-tone tile: its B operand (the phasor table) is loaded into registers
+// once per wave, its A operand is the input stream times the taps.  Both are
+// split into fp16 hi + lo and the three leading products are kept
+// (hi*hi + hi*lo + lo*hi), which carries ~22 bits: scratch/mfma_sim.py measures
+// 1e-7..3e-7 relative error per tone against fp64.  P and rot are applied in
+// fp32 on the VALU (2*F/PK packed instructions per tone-sample instead of 2+F).
+// S is a power of two that puts max|b| near 2^13: fp16 holds 2^16, so nothing
+// overflows and the lo halves stay normal; it comes from absmax_kernel's pass
+// over the buffer (max over this and the previous buffer, whose tail is the carry).
+//
+// Work split: one wave = 32 output rows x TT tiles of 32 tones; the four waves
+// of a workgroup take four tone groups of the same rows (they read the same x
+// through the CU's L1), and workgroups of the same rows sit on one XCD.
+#include <cmath>
+#include <type_traits>
+#include <vector>
+
+#include "ddc_device.h"
+
+namespace gsdr {
+
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef float float4u __attribute__((ext_vector_type(4), aligned(8)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+namespace {
+
+struct Frag {
+    half8 hi, lo;
+};
+
+// one complex sample times its (scaled) tap, split into fp16 hi and lo
+__device__ __forceinline__ void split_pair(float xr, float xi, float hs, half2v &hi, half2v &lo) {
+    const float2v v = {xr * hs, xi * hs};
+    hi = __builtin_convertvector(v, half2v);
+    const float2v res = v - __builtin_convertvector(hi, float2v);
+    lo = __builtin_convertvector(res, half2v);
+}
+
+__device__ __forceinline__ Frag make_frag(const float4v xa, const float4v xb, const float4v hs) {
+    half2v h0, h1, h2, h3, l0, l1, l2, l3;
+    split_pair(xa.x, xa.y, hs.x, h0, l0);
+    split_pair(xa.z, xa.w, hs.y, h1, l1);
+    split_pair(xb.x, xb.y, hs.z, h2, l2);
+    split_pair(xb.z, xb.w, hs.w, h3, l3);
+    Frag f;
+    const half4v ha = __builtin_shufflevector(h0, h1, 0, 1, 2, 3);
+    const half4v hb = __builtin_shufflevector(h2, h3, 0, 1, 2, 3);
+    const half4v la = __builtin_shufflevector(l0, l1, 0, 1, 2, 3);
+    const half4v lb = __builtin_shufflevector(l2, l3, 0, 1, 2, 3);
+    f.hi = __builtin_shufflevector(ha, hb, 0, 1, 2, 3, 4, 5, 6, 7);
+    f.lo = __builtin_shufflevector(la, lb, 0, 1, 2, 3, 4, 5, 6, 7);
+    return f;
+}
+
+}  // namespace
+
+// Workgroup barrier that no LDS access may be scheduled across (asm + memory
+// clobber: the compiler was seen to move ring reads over a plain s_barrier).
+__device__ __forceinline__ void wg_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// One workgroup = W waves on the same 32 output rows, one tone group (TT tiles of
+// 32 tones) per wave.  The A operand (input x taps, split into fp16 hi/lo) does
+// not depend on the tone: the waves produce it once, W-way split, into an LDS
+// ring of two phasor blocks, and every wave reads all of it back as MFMA
+// operands.  One barrier per block of PK samples.
+//
+// The kernel has no boundary cases in its loads: rows that reach before x[0]
+// (the carry) or past its end are served from the head / tail copies that
+// absmax_kernel lays out ([carry | first rows] and [last rows | zeros]); every
+// block is a whole block (taps zero padded to nhi*PK samples).
+//
+// Ordering inside one iteration is pinned with sched_barrier(0):
+//   barrier | LDS reads of the block | convert next block -> LDS, loads of the one
+//   after | MFMAs | wait | P*C on the VALU.
+// Two hazards were measured on gfx950 (scratch/mfma_diag*.py) that the compiler
+// does not guard against, and this order keeps clear of both:
+//   * an LDS (or scratch) load returning into a register that an MFMA issued a few
+//     instructions earlier reads as A/B operand: rows 16..31 of that MFMA were
+//     computed from the NEW contents.  Here the operand registers are rewritten
+//     only after the barrier that follows the VALU pass over all 32 results.
+//   * VALU reads of a VGPR-form MFMA result behind the compiler's own s_nop count
+//     returned stale upper registers (8..15); an explicit wait precedes them.
+template <int TT, int PK, int W, int SGB>
+__global__ __launch_bounds__(64 * W, TT == 1 ? 2 : 1) void ddc_mfma_kernel(const MfmaLaunch a) {
+    constexpr int KS = PK / 8;    // MFMA k-steps (8 complex samples each) per phasor block
+    constexpr int SPW = KS / W;   // k-steps each wave produces per block
+    static_assert(KS % W == 0 && SPW >= 1, "every wave produces whole k-steps");
+    __shared__ uint4 ring[2][KS][2][64];
+    const MfmaShape &sh = a.sh;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar
+    const int r = lane & 31, hh = lane >> 5;
+    // workgroup -> (row tile, tone-group W-tuple): blockIdx % 8 is the XCD, and all
+    // tone groups of one row tile go to the same XCD (one copy of x per L2)
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int gt = (q / sh.ntq) * 8 + xcd;
+    if (gt >= sh.ngt) return;     // whole workgroup
+    const int tg_raw = (q % sh.ntq) * W + wave;
+    const bool active = tg_raw < sh.ntg;      // idle waves still produce and keep the barriers
+    const int tg = active ? tg_raw : sh.ntg - 1;
+
+    // ---- constant operand: phasor table fragments, register resident ----
+    half8 Bf[TT][KS][2][2];
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp) {
+                    const size_t at = ((((size_t)(tg * TT + tt) * KS + ks) * 2 + c) * 2 + sp) * 64 + lane;
+                    const uint4 v = a.bfrag[at];
+                    Bf[tt][ks][c][sp] = __builtin_bit_cast(half8, v);
+                }
+
+    // ---- scale from the absmax pass ----
+    const unsigned mb0 = a.maxbits[sh.slot_cur], mb1 = a.maxbits[sh.slot_prev];
+    const unsigned mb = mb0 > mb1 ? mb0 : mb1;
+    int se = 140 - (int)((mb >> 23) & 0xffu);       // |x| < 2^(e-126), |h'| <= 1  =>  |b| < 2^14
+    se = se > 100 ? 100 : (se < -100 ? -100 : se);
+    const float S = __uint_as_float((unsigned)(127 + se) << 23);
+    const float invS = __uint_as_float((unsigned)(127 - se) << 23) * sh.unscale;
+
+    // ---- this lane's row of the A operand ----
+    const int o = gt * 32 + r;
+    const int oc = o < sh.nout ? o : sh.nout - 1;
+    // head: sample s lives at head[s + carry_len]; tail: at tail[s - tail0]
+    const float2 *xbase = gt == 0 ? a.head + sh.carry_len
+                                  : (gt == sh.ngt - 1 ? a.tail - sh.tail0 : a.x);
+    const float2 *xrow = xbase + ((long long)(oc + sh.woff) * sh.M + 4 * hh);
+    const float *tp = a.taps + 4 * hh;
+
+    const int nhi = (sh.nk8 + KS - 1) / KS;
+    float4v xa[SPW], xb[SPW], hv[SPW];
+    auto gload = [&](int blk) {   // blocks past the last one: clamped, valid addresses, results unused
+        const int bc = blk < nhi ? blk : nhi - 1;
+#pragma unroll
+        for (int j = 0; j < SPW; ++j) {
+            const int k = bc * KS + wave + j * W;
+            hv[j] = *reinterpret_cast<const float4v *>(tp + 8 * k);
+            const float4u *p = reinterpret_cast<const float4u *>(xrow + 8 * k);
+            xa[j] = p[0];
+            xb[j] = p[1];
+        }
+    };
+    auto produce = [&](int slot) {
+#pragma unroll
+        for (int j = 0; j < SPW; ++j) {
+            const int ks = wave + j * W;
+            const Frag f = make_frag(xa[j], xb[j], hv[j] * S);
+            ring[slot][ks][0][lane] = __builtin_bit_cast(uint4, f.hi);
+            ring[slot][ks][1][lane] = __builtin_bit_cast(uint4, f.lo);
+        }
+    };
+
+    float16v accr[TT], acci[TT];
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) accr[tt][i] = acci[tt][i] = 0.f;
+
+    const int Np = sh.NT32 * 32;
+    const int n0 = tg * TT * 32 + r;   // this lane's tone in tile 0
+    const float2 *pp = a.ptab + n0;
+
+    gload(0);
+    produce(0);
+    gload(1);
+    for (int hi = 0; hi < nhi; ++hi) {
+        const int slot = hi & 1;
+        wg_barrier();   // block hi is in the ring; the other slot is free again
+        half8 fh[KS], fl[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            fh[ks] = __builtin_bit_cast(half8, ring[slot][ks][0][lane]);
+            fl[ks] = __builtin_bit_cast(half8, ring[slot][ks][1][lane]);
+        }
+        float2 P[TT];
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) P[tt] = pp[(size_t)hi * Np + tt * 32];
+        produce(slot ^ 1);
+        gload(hi + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        float16v Cr[TT], Ci[TT];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const float16v zero = {0};
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) {
+                float16v cr = ks == 0 ? zero : Cr[tt], ci = ks == 0 ? zero : Ci[tt];
+                cr = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ks], Bf[tt][ks][0][0], cr, 0, 0, 0);
+                ci = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ks], Bf[tt][ks][1][0], ci, 0, 0, 0);
+                cr = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ks], Bf[tt][ks][0][1], cr, 0, 0, 0);
+                ci = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ks], Bf[tt][ks][1][1], ci, 0, 0, 0);
+                cr = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[ks], Bf[tt][ks][0][0], cr, 0, 0, 0);
+                ci = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[ks], Bf[tt][ks][1][0], ci, 0, 0, 0);
+                Cr[tt] = cr;
+                Ci[tt] = ci;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 15\n\ts_nop 15");   // see the header: results first, then their readers
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                accr[tt][i] = __builtin_fmaf(P[tt].x, Cr[tt][i], accr[tt][i]);
+                accr[tt][i] = __builtin_fmaf(-P[tt].y, Ci[tt][i], accr[tt][i]);
+                acci[tt][i] = __builtin_fmaf(P[tt].x, Ci[tt][i], acci[tt][i]);
+                acci[tt][i] = __builtin_fmaf(P[tt].y, Cr[tt][i], acci[tt][i]);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!active) return;
+
+    // ---- rot[n,o] = w_n^(idx_base + o*M) / S, stores ----
+    const unsigned long long s_tile = mod_rate(
+        (unsigned long long)sh.idx_base + (unsigned long long)(gt * 32) * sh.m_mod_rate, sh.rate, sh.rate_magic);
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+        const int n = n0 + tt * 32;
+        const unsigned long long ph = mod_rate((unsigned long long)a.fmod[n] * s_tile, sh.rate, sh.rate_magic);
+        double bre, bim;
+        exact_phasor(ph, sh.inv_rate, bre, bim);
+        const float br = (float)bre * invS, bi = (float)bim * invS;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
+            const float2 d = a.dtab[(size_t)row * Np + n];
+            const float rr = br * d.x - bi * d.y, ri = br * d.y + bi * d.x;
+            float2 y;
+            y.x = accr[tt][i] * rr - acci[tt][i] * ri;
+            y.y = accr[tt][i] * ri + acci[tt][i] * rr;
+            const int orow = gt * 32 + row;
+            if (orow < sh.nout && n < sh.N) a.out[(size_t)orow * sh.N + n] = y;
+        }
+    }
+}
+
+// One pass over the new buffer x[0..n):
+//   * max |component| as float bits -> atomicMax(slots[cur]); slots[next] = 0;
+//   * head_cur[carry_len + i] = x[i] for i < head_n (row tile 0 reads [carry | x) there);
+//   * head_next[i - (n - carry_len)] = x[i] for the last carry_len samples (next call's carry);
+//   * tail[i - tail0] = x[i] for i >= tail0 (the last row tile reads there; zeros follow).
+// All destinations may be null.
+__global__ __launch_bounds__(256) void absmax_kernel(const float2 *x, long long n, unsigned *slots,
+                                                     int cur, int next, float2 *head_cur,
+                                                     long long head_n, float2 *head_next,
+                                                     int carry_len, float2 *tail, long long tail0) {
+    const long long tid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long stride = (long long)gridDim.x * 256;
+    unsigned m = 0;
+    for (long long i = tid; i < n; i += stride) {
+        const float2 v = x[i];
+        const unsigned b0 = __float_as_uint(v.x) & 0x7fffffffu, b1 = __float_as_uint(v.y) & 0x7fffffffu;
+        const unsigned t = b0 > b1 ? b0 : b1;
+        m = m > t ? m : t;
+        if (head_cur && i < head_n) head_cur[carry_len + i] = v;
+        if (head_next && i >= n - carry_len) head_next[i - (n - carry_len)] = v;
+        if (tail && i >= tail0) tail[i - tail0] = v;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned t = (unsigned)__shfl_xor((int)m, d);
+        m = m > t ? m : t;
+    }
+    // one atomic per workgroup: thousands of same-address atomics serialise
+    __shared__ unsigned wmax[4];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned u = wmax[0] > wmax[1] ? wmax[0] : wmax[1], w = wmax[2] > wmax[3] ? wmax[2] : wmax[3];
+        const unsigned t = u > w ? u : w;
+        if (t) atomicMax(&slots[cur], t);
+    }
+    if (tid == 0) slots[next] = 0u;
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+namespace {
+
+unsigned short to_half_bits(float v) {
+    const _Float16 h = (_Float16)v;   // round to nearest even, like v_cvt_pk_f16_f32
+    unsigned short b;
+    __builtin_memcpy(&b, &h, 2);
+    return b;
+}
+float from_half_bits(unsigned short b) {
+    _Float16 h;
+    __builtin_memcpy(&h, &b, 2);
+    return (float)h;
+}
+
+void host_phasor(unsigned long long ph, unsigned rate, double &re, double &im) {
+    const double ang = 2.0 * M_PI * ((double)ph / (double)rate);
+    re = std::cos(ang);
+    im = -std::sin(ang);
+}
+
+template <int TT, int PK, int W>
+hipError_t launch_tpw(int sgb, const MfmaLaunch &a, hipStream_t st) {
+    const int gt8 = (a.sh.ngt + 7) / 8;
+    const long long grid = (long long)gt8 * 8 * a.sh.ntq;
+    if (grid < 1 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
+    const dim3 g((unsigned)grid), b(64 * W);
+    switch (sgb) {
+        case 0: hipLaunchKernelGGL((ddc_mfma_kernel<TT, PK, W, 0>), g, b, 0, st, a); break;
+        case 2: hipLaunchKernelGGL((ddc_mfma_kernel<TT, PK, W, 2>), g, b, 0, st, a); break;
+        case 3: hipLaunchKernelGGL((ddc_mfma_kernel<TT, PK, W, 3>), g, b, 0, st, a); break;
+        case 4: hipLaunchKernelGGL((ddc_mfma_kernel<TT, PK, W, 4>), g, b, 0, st, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+template <int TT, int PK>
+hipError_t launch_tp(int W, int sgb, const MfmaLaunch &a, hipStream_t st) {
+    switch (W) {
+        case 2: return launch_tpw<TT, PK, 2>(sgb, a, st);
+        case 4: if constexpr (PK >= 32) return launch_tpw<TT, PK, 4>(sgb, a, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace
+
+void mfma_build_tables(const MfmaPlan &pl, const std::vector<unsigned> &fmod_in, const float *window,
+                       std::vector<uint4> &bfrag, std::vector<float2> &ptab,
+                       std::vector<float2> &dtab, std::vector<float> &taps,
+                       std::vector<unsigned> &fmod, float &unscale) {
+    const int KS = pl.PK / 8;
+    const int tiles = pl.ntg * pl.TT, Np = tiles * 32;
+    const unsigned rate = pl.rate;
+    fmod.assign(Np, 0u);
+    for (size_t n = 0; n < fmod_in.size() && n < (size_t)Np; ++n) fmod[n] = fmod_in[n];
+    // B operand images: lane (r, hh), element j  <->  k = 8*hh + j  <->  sample
+    // lo = 8*ks + 4*hh + (j >> 1), component j & 1 (0: pairs with Re b, 1: with Im b).
+    //   c = 0 (real part of the product):  [ Wr, -Wi ]
+    //   c = 1 (imaginary part):            [ Wi,  Wr ]
+    bfrag.assign((size_t)tiles * KS * 4 * 64, uint4{0, 0, 0, 0});
+    for (int T = 0; T < tiles; ++T)
+        for (int ks = 0; ks < KS; ++ks)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int r = lane & 31, hh = lane >> 5;
+                const unsigned long long fm = fmod[(size_t)T * 32 + r];
+                unsigned short img[2][2][8];
+                for (int j = 0; j < 8; ++j) {
+                    const int lo = 8 * ks + 4 * hh + (j >> 1);
+                    double wr, wi;
+                    host_phasor((fm * (unsigned long long)lo) % rate, rate, wr, wi);
+                    const float v[2] = {(j & 1) ? (float)-wi : (float)wr, (j & 1) ? (float)wr : (float)wi};
+                    for (int c = 0; c < 2; ++c) {
+                        const unsigned short hb = to_half_bits(v[c]);
+                        img[c][0][j] = hb;
+                        img[c][1][j] = to_half_bits(v[c] - from_half_bits(hb));
+                    }
+                }
+                for (int c = 0; c < 2; ++c)
+                    for (int sp = 0; sp < 2; ++sp) {
+                        uint4 w;
+                        __builtin_memcpy(&w, img[c][sp], 16);
+                        bfrag[((((size_t)T * KS + ks) * 2 + c) * 2 + sp) * 64 + lane] = w;
+                    }
+            }
+    const int nhi = (pl.nk8 + KS - 1) / KS;
+    ptab.resize((size_t)nhi * Np);
+    for (int hi = 0; hi < nhi; ++hi)
+        for (int n = 0; n < Np; ++n) {
+            double re, im;
+            host_phasor(((unsigned long long)fmod[n] * (((unsigned long long)hi * pl.PK) % rate)) % rate, rate, re, im);
+            ptab[(size_t)hi * Np + n] = make_float2((float)re, (float)im);
+        }
+    dtab.resize((size_t)32 * Np);
+    for (int row = 0; row < 32; ++row)
+        for (int n = 0; n < Np; ++n) {
+            double re, im;
+            host_phasor(((unsigned long long)fmod[n] * (((unsigned long long)row * pl.M) % rate)) % rate, rate, re, im);
+            dtab[(size_t)row * Np + n] = make_float2((float)re, (float)im);
+        }
+    // taps scaled by a power of two to max |h'| in (1/2, 1], zero padded to whole k-steps
+    float hmax = 0.f;
+    for (int t = 0; t < pl.MF; ++t) hmax = std::fmax(hmax, std::fabs(window[t]));
+    int eh = 0;
+    if (hmax > 0.f) {
+        (void)std::frexp(hmax, &eh);   // hmax = m * 2^eh, m in [0.5, 1)
+    }
+    unscale = std::ldexp(1.f, eh);
+    taps.assign((size_t)nhi * pl.PK + 8, 0.f);   // whole blocks, zero padded
+    for (int t = 0; t < pl.MF; ++t) taps[t] = std::ldexp(window[t], -eh);
+}
+
+hipError_t launch_absmax(const float2 *x, long long n, unsigned *slots, int cur, int next,
+                         float2 *head_cur, long long head_n, float2 *head_next, int carry_len,
+                         float2 *tail, long long tail0, hipStream_t st) {
+    if (n < 1 || carry_len < 0 || carry_len > n || head_n < 0 || head_n > n || tail0 < 0 || tail0 > n)
+        return hipErrorInvalidValue;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n, slots, cur, next,
+                       head_cur, head_n, head_next, carry_len, tail, tail0);
+    return hipGetLastError();
+}
+
+hipError_t launch_ddc_mfma(int TT, int PK, int W, int sgb, const MfmaLaunch &a, hipStream_t st) {
+    const MfmaShape &sh = a.sh;
+    // shapes are checked on the host: a kernel reading past its tables faults the GPU
+    if (sh.N < 1 || sh.nout < 1 || sh.M < 1 || sh.MF < 1 || sh.nk8 != (sh.MF + 7) / 8 ||
+        sh.ngt != (sh.nout + 31) / 32 || sh.ntg < 1 || W < 1 || sh.ntq != (sh.ntg + W - 1) / W ||
+        sh.NT32 != sh.ntg * TT || sh.N > sh.NT32 * 32 || sh.rate < 1 ||
+        (long long)(sh.nout - 1 + sh.woff) * sh.M + sh.MF > sh.nx ||
+        (long long)sh.woff * sh.M + sh.carry_len < 0 || (sh.woff < 0 && -sh.woff > 32) ||
+        !a.x || !a.head || !a.tail || !a.out || !a.bfrag || !a.ptab || !a.dtab || !a.taps ||
+        !a.fmod || !a.maxbits)
+        return hipErrorInvalidValue;
+    // the row tiles between the first and the last read a.x directly, 8 samples at a time
+    // (TONES passes its own over-allocated window as x, head and tail alike); a row
+    // reads `reach` samples from its start: whole phasor blocks
+    const long long reach = (long long)((sh.nk8 + PK / 8 - 1) / (PK / 8)) * PK;
+    if (a.x != a.tail && sh.ngt > 2 && (long long)(32 * (sh.ngt - 1) - 1 + sh.woff) * sh.M + reach > sh.nx)
+        return hipErrorInvalidValue;
+    if (sh.ngt > 1 && (long long)(32 * (sh.ngt - 1) + sh.woff) * sh.M < sh.tail0) return hipErrorInvalidValue;
+    if (TT == 2 && PK == 32) return launch_tp<2, 32>(W, sgb, a, st);
+    if (TT == 1 && PK == 32) return launch_tp<1, 32>(W, sgb, a, st);
+    if (TT == 2 && PK == 16) return launch_tp<2, 16>(W, sgb, a, st);
+    if (TT == 1 && PK == 16) return launch_tp<1, 16>(W, sgb, a, st);
+    return hipErrorInvalidValue;
+}
+
+const char *ddc_mfma_kernel_name() { return "ddc_mfma_kernel"; }
+
+}  // namespace gsdr

@@ -88,6 +88,19 @@ struct gsdr_demod {
     float2 *d_tails = nullptr;
     float2 *d_carry[2] = {nullptr, nullptr};
     int parity = 0;
+    // ---- DDC on the matrix cores (ddc_mfma.hip) ----
+    bool mfma = false;
+    int mf_TT = 1, mf_PK = 32, mf_W = 4;   // tone tiles per wave, phasor block, waves per workgroup
+    int mf_sgb = 4;                        // VALU instructions scheduled behind each MFMA (0: compiler's order)
+    gsdr::MfmaShape mf{};              // fields that do not change between calls
+    uint4 *d_bfrag = nullptr;
+    float2 *d_ptab = nullptr, *d_dtab = nullptr;
+    float *d_mtaps = nullptr;
+    unsigned *d_mfmod = nullptr, *d_maxbits = nullptr;
+    float2 *d_head[2] = {nullptr, nullptr};     // [carry | first rows' samples | zeros], see absmax_kernel
+    float2 *d_tail = nullptr;                   // [last rows' samples | zeros]
+    int xparity = 0;
+    unsigned long long call_no = 0;    // absmax slot rotation
     // ---- TONES ----
     std::vector<int> bins;
     int nfft = 0, batching = 0;
@@ -313,6 +326,86 @@ void finish_shape(DdcShape &sh) {
     sh.m_mod_rate = (unsigned)sh.M % sh.rate;
 }
 
+// Tables and fixed shape of ddc_mfma_kernel.  `direct`: rows reach F-1 blocks
+// back into the previous buffer (raw-sample carry); otherwise (TONES/NOISE) row o
+// starts at block o of the raw window.
+int setup_mfma(gsdr_demod *h, bool direct, const std::vector<long long> &tone) {
+    const int F = h->F, M = h->M;
+    const unsigned rate = h->nco_rate;
+    h->mf_TT = env_int("GSDR_MFMA_TT", 1) == 2 ? 2 : 1;
+    h->mf_PK = env_int("GSDR_MFMA_PK", 32) == 16 ? 16 : 32;
+    h->mf_W = env_int("GSDR_MFMA_W", 4);
+    if (h->mf_W != 2 && h->mf_W != 4) h->mf_W = 4;
+    h->mf_sgb = env_int("GSDR_MFMA_SGB", 4);
+    if (h->mf_sgb != 0 && h->mf_sgb != 2 && h->mf_sgb != 3) h->mf_sgb = 4;
+    if (h->mf_W > h->mf_PK / 8) h->mf_W = h->mf_PK / 8;
+    gsdr::MfmaPlan pl{};
+    pl.TT = h->mf_TT;
+    pl.PK = h->mf_PK;
+    pl.M = M;
+    pl.MF = M * F;
+    pl.nk8 = (pl.MF + 7) / 8;
+    pl.rate = rate;
+    const int nt32 = (h->ddc_channels + 31) / 32;
+    pl.ntg = (nt32 + pl.TT - 1) / pl.TT;
+    std::vector<unsigned> fmod_in(h->ddc_channels);
+    for (int n = 0; n < h->ddc_channels; ++n) {
+        long long r = tone[n] % (long long)rate;
+        if (r < 0) r += rate;
+        fmod_in[n] = (unsigned)r;
+    }
+    std::vector<uint4> bfrag;
+    std::vector<float2> ptab, dtab;
+    std::vector<float> taps;
+    std::vector<unsigned> fmod;
+    float unscale = 1.f;
+    gsdr::mfma_build_tables(pl, fmod_in, h->window.data(), bfrag, ptab, dtab, taps, fmod, unscale);
+    HIPCHK(h, upload(&h->d_bfrag, bfrag));
+    HIPCHK(h, upload(&h->d_ptab, ptab));
+    HIPCHK(h, upload(&h->d_dtab, dtab));
+    HIPCHK(h, upload(&h->d_mtaps, taps));
+    HIPCHK(h, upload(&h->d_mfmod, fmod));
+    HIPCHK(h, dev_alloc(&h->d_maxbits, 4));
+    HIPCHK(h, hipMemset(h->d_maxbits, 0, 4 * sizeof(unsigned)));
+    gsdr::MfmaShape &sh = h->mf;
+    sh.N = h->ddc_channels;
+    sh.NT32 = pl.ntg * pl.TT;
+    sh.ntg = pl.ntg;
+    sh.ntq = (pl.ntg + h->mf_W - 1) / h->mf_W;
+    sh.M = M;
+    sh.MF = pl.MF;
+    sh.nk8 = pl.nk8;
+    sh.woff = direct ? -(F - 1) : 0;
+    sh.carry_len = direct ? (F - 1) * M : 0;
+    sh.rate = rate;
+    sh.rate_magic = 0xffffffffffffffffULL / rate;
+    sh.inv_rate = 1.0 / (double)rate;
+    sh.m_mod_rate = (unsigned)M % rate;
+    sh.unscale = unscale;
+    if (direct) {
+        // row tile 0 and the last row tile read from copies with the carry in front
+        // and zeros behind (sizes: ddc_mfma_kernel's reach, 8*nk8 samples per row)
+        const size_t reach = (size_t)((pl.nk8 + pl.PK / 8 - 1) / (pl.PK / 8)) * pl.PK;   // whole phasor blocks
+        const size_t head_n = (size_t)sh.carry_len + 32u * (size_t)M + reach + 8;
+        const size_t tail_n = (size_t)(32 + F) * (size_t)M + reach + 8;
+        for (int i = 0; i < 2; ++i) {
+            HIPCHK(h, dev_alloc(&h->d_head[i], head_n));
+            HIPCHK(h, hipMemset(h->d_head[i], 0, head_n * sizeof(float2)));
+        }
+        HIPCHK(h, dev_alloc(&h->d_tail, tail_n));
+        HIPCHK(h, hipMemset(h->d_tail, 0, tail_n * sizeof(float2)));
+    }
+    h->mfma = true;
+    h->kernel_name = gsdr::ddc_mfma_kernel_name();
+    return 0;
+}
+
+// absmax pass over `in` + ddc_mfma_kernel over `nout` rows.  DIRECT: raw == nullptr,
+// the rows read `in` (and its head/tail copies).  TONES: the pass also appends
+// `in` to the raw window at raw_new0 and the rows read raw[0 .. nx).
+int enqueue_mfma(gsdr_demod *h, const float2 *in, float2 *raw, long long raw_new0, long long nx,
+                 int nout, unsigned idx_base, float2 *out, hipStream_t st);
+
 int record_begin(gsdr_demod *h, hipStream_t st, hipEvent_t *stop) {
     *stop = nullptr;
     if (!h->prof || h->ev_used >= (size_t)kMaxEvents) return 0;
@@ -411,6 +504,54 @@ int autotune_chunks(gsdr_demod *h, int nblk) {
     return 0;
 }
 
+int enqueue_mfma(gsdr_demod *h, const float2 *in, float2 *raw, long long raw_new0, long long nx,
+                 int nout, unsigned idx_base, float2 *out, hipStream_t st) {
+    const int cur = (int)(h->call_no % 3), prev = (int)((h->call_no + 2) % 3),
+              next = (int)((h->call_no + 1) % 3);
+    gsdr::MfmaLaunch a{};
+    a.sh = h->mf;
+    a.sh.nout = nout;
+    a.sh.ngt = (nout + 31) / 32;
+    a.sh.nx = nx;
+    a.sh.idx_base = idx_base;
+    a.sh.slot_cur = cur;
+    a.sh.slot_prev = prev;
+    if (raw) {
+        // TONES: one pass appends the buffer to the raw window and takes its maximum;
+        // every row reads the window itself (allocated twice as long as it gets)
+        HIPCHK(h, gsdr::launch_absmax(in, h->L, h->d_maxbits, cur, next, raw + raw_new0, h->L, nullptr, 0,
+                                      nullptr, h->L, st));
+        a.x = a.head = a.tail = raw;
+        a.sh.tail0 = 0;
+    } else {
+        const int cl = a.sh.carry_len;
+        const long long t0 = a.sh.ngt > 1 ? (long long)(32 * (a.sh.ngt - 1) + a.sh.woff) * a.sh.M : h->L;
+        const int ks = h->mf_PK / 8;
+        long long head_n = 32LL * a.sh.M + (long long)((a.sh.nk8 + ks - 1) / ks) * h->mf_PK + 8;
+        if (head_n > h->L) head_n = h->L;
+        HIPCHK(h, gsdr::launch_absmax(in, h->L, h->d_maxbits, cur, next, h->d_head[h->xparity], head_n,
+                                      h->d_head[h->xparity ^ 1], cl, h->d_tail, t0, st));
+        a.x = in;
+        a.head = h->d_head[h->xparity];
+        a.tail = h->d_tail;
+        a.sh.tail0 = t0;
+        h->xparity ^= 1;
+    }
+    a.taps = h->d_mtaps;
+    a.bfrag = h->d_bfrag;
+    a.ptab = h->d_ptab;
+    a.dtab = h->d_dtab;
+    a.fmod = h->d_mfmod;
+    a.maxbits = h->d_maxbits;
+    a.out = out;
+    hipEvent_t stop = nullptr;
+    if (record_begin(h, st, &stop)) return -1;
+    HIPCHK(h, gsdr::launch_ddc_mfma(h->mf_TT, h->mf_PK, h->mf_W, h->mf_sgb, a, st));
+    if (stop) HIPCHK(h, hipEventRecord(stop, st));
+    h->call_no++;
+    return 0;
+}
+
 // ref: process_direct, cpp/USRP_demodulator.cpp:400-464
 int enqueue_direct(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t st) {
     DdcLaunch a{};
@@ -433,7 +574,13 @@ int enqueue_direct(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t st)
     a.sh.g_off = 0;
     long long ret;
     hipEvent_t stop = nullptr;
-    if (h->decim > 0) {
+    if (h->decim > 0 && h->mfma) {
+        const unsigned rate = h->nco_rate;
+        const unsigned back = (unsigned)(((unsigned long long)(h->F - 1) * h->M) % rate);
+        const unsigned idx_base = (unsigned)((h->idx + rate - back) % rate);
+        if (enqueue_mfma(h, in, nullptr, 0, h->L, (int)(h->L / h->M), idx_base, out, st)) return -1;
+        ret = (long long)h->N * (h->L / h->M);               // :459
+    } else if (h->decim > 0) {
         a.tails = h->d_tails;
         a.tails_nch = h->tails_nch;
         a.carry_in = h->d_carry[h->parity];
@@ -476,10 +623,14 @@ int enqueue_direct(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t st)
 // ref: process_pfb (decim == 0 branch), cpp/USRP_demodulator.cpp:486-565
 int enqueue_pfb(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t st) {
     // :491-495  new buffer goes after the carried samples
-    HIPCHK(h, hipMemcpyAsync(h->d_raw + h->bh.new_0, in, (size_t)h->L * sizeof(float2),
-                             hipMemcpyDeviceToDevice, st));
     const int cb = h->bh.current_batch;
-    if (cb > 0) {
+    if (!(cb > 0 && h->mfma))
+        HIPCHK(h, hipMemcpyAsync(h->d_raw + h->bh.new_0, in, (size_t)h->L * sizeof(float2),
+                                 hipMemcpyDeviceToDevice, st));
+    if (cb > 0 && h->mfma) {
+        if (enqueue_mfma(h, in, h->d_raw, h->bh.new_0, (long long)(cb + h->F - 1) * h->M, cb, 0u, out, st))
+            return -1;
+    } else if (cb > 0) {
         DdcLaunch a{};
         a.x = h->d_raw;
         a.taps_t = h->d_taps_t;
@@ -670,7 +821,12 @@ gsdr_demod *gsdr_demod_create(const gsdr_param_c *p) {
                         }
                     }
                 }
-                if (!rc) rc = autotune_chunks(h, (int)(h->L / M));
+                // (rows read whole 32-sample phasor blocks: the padding behind a window must stay
+                //  within the next block, or middle rows would read past the buffer)
+                if (!rc && env_int("GSDR_DDC_MFMA", 0) != 0 && h->L / M >= F - 1 && h->L >= 4 && F <= 33 &&
+                    (M * F + 31) / 32 * 32 - M * F <= M)
+                    rc = setup_mfma(h, /*direct=*/true, tone);
+                if (!rc && !h->mfma) rc = autotune_chunks(h, (int)(h->L / M));
                 h->capacity = (long long)h->N * (h->L / M);
             } else {
                 // undecimated: only the NCO tables are needed
@@ -728,7 +884,13 @@ gsdr_demod *gsdr_demod_create(const gsdr_param_c *p) {
                     rc = -1;
                 }
             }
-            if (!rc) rc = autotune_chunks(h, (int)(h->L / h->nfft) + F - 1);
+            // every carried sample of the raw window must come from the previous buffer
+            // (absmax covers this buffer and the one before)
+            // and the padding behind the last window must stay inside the raw buffer's spare half
+            if (!rc && env_int("GSDR_DDC_MFMA", 0) != 0 && (long long)h->nfft * (F + 1) <= h->L &&
+                (long long)h->nfft * h->batching >= 40)
+                rc = setup_mfma(h, /*direct=*/false, tone);
+            if (!rc && !h->mfma) rc = autotune_chunks(h, (int)(h->L / h->nfft) + F - 1);
             h->capacity = (long long)n_ch * h->batching;               // :147 / :288
             break;
         }
@@ -908,7 +1070,9 @@ void gsdr_demod_close(gsdr_demod *h) {
     }
     void *ptrs[] = {h->d_in,      h->d_out,     h->d_taps_t,   h->d_taps_p,   h->d_stage,    h->d_btab,     h->d_wk,
                     h->d_wrem,    h->d_fmod,    h->d_tails,    h->d_carry[0], h->d_carry[1],
-                    h->d_raw,     h->d_profile, h->d_ccarry[0], h->d_ccarry[1]};
+                    h->d_raw,     h->d_profile, h->d_ccarry[0], h->d_ccarry[1],
+                    h->d_bfrag,   h->d_ptab,    h->d_dtab,     h->d_mtaps,    h->d_mfmod,
+                    h->d_maxbits, h->d_head[0], h->d_head[1], h->d_tail};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);  // ref: 03_implement.md:58-63

@@ -68,12 +68,19 @@ def make_chirp(rate, f0, f1, steps, t, decim, L):
     return g.RX_buffer_demodulator(p, device_index=0)
 
 
+@pytest.fixture(params=["flat", "mfma"])
+def engine(request, monkeypatch):
+    """Runs a test once per DDC engine: packed-FP32 VALU kernel, matrix-core kernel."""
+    monkeypatch.setenv("GSDR_DDC_MFMA", "1" if request.param == "mfma" else "0")
+    return request.param
+
+
 # ---------------------------------------------------------------------------
 # frozen fixtures
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize("name", ["direct", "pfb", "chirp"])
 @pytest.mark.parametrize("entry", ["host", "device"])
-def test_golden_fixture(cuda_device, gsdr_lib, name, entry):
+def test_golden_fixture(cuda_device, gsdr_lib, name, entry, engine):
     g = np.load(os.path.join(HERE, "golden", f"{name}.npz"), allow_pickle=False)
     cfg = json.loads(str(g["config"]))
     L = cfg["buffer_len"]
@@ -117,13 +124,27 @@ DIRECT_CASES = [
 
 
 @pytest.mark.parametrize("case", DIRECT_CASES, ids=lambda c: "N%d_M%d_F%d_L%d" % (c[0], c[2], c[3], c[4]))
-@pytest.mark.parametrize("impl", ["flat", "flat12", "flat16", "flat20", "simple16", "simple32"])
+@pytest.mark.parametrize("impl", ["flat", "flat12", "flat16", "flat20", "simple16", "simple32",
+                                  "mfma", "mfma_t2", "mfma_w2", "mfma_pk16"])
 def test_direct_parity(cuda_device, gsdr_lib, oracle_mod, monkeypatch, case, impl):
-    """flat* = ddc_flat_kernel (production; sub-block length auto / forced),
-    simple* = ddc_kernel (generic fallback, phasor table 16 / 32)."""
+    """flat* = ddc_flat_kernel (packed FP32; sub-block length auto / forced),
+    simple* = ddc_kernel (generic fallback, phasor table 16 / 32),
+    mfma* = ddc_mfma_kernel (split-fp16 matrix cores; tone tiles per wave 1/2, waves per
+    workgroup 4/1/2, phasor block 32/16)."""
     N, rate, M, F, L, nbuf = case
-    monkeypatch.setenv("GSDR_DDC_PIPE", "1" if impl.startswith("flat") else "0")
-    monkeypatch.setenv("GSDR_DDC_K", impl.lstrip("flatsimple") or "0")
+    if impl.startswith("mfma"):
+        monkeypatch.setenv("GSDR_DDC_MFMA", "1")
+        if "_t" in impl:
+            monkeypatch.setenv("GSDR_MFMA_TT", impl[-1])
+        if "_w" in impl:
+            monkeypatch.setenv("GSDR_MFMA_W", impl[-1])
+            monkeypatch.setenv("GSDR_MFMA_SGB", "0")
+        if "_pk" in impl:
+            monkeypatch.setenv("GSDR_MFMA_PK", impl[-2:])
+    else:
+        monkeypatch.setenv("GSDR_DDC_MFMA", "0")
+        monkeypatch.setenv("GSDR_DDC_PIPE", "1" if impl.startswith("flat") else "0")
+        monkeypatch.setenv("GSDR_DDC_K", impl.lstrip("flatsimple") or "0")
     rng = np.random.default_rng(1000 + N + M)
     freq = rng.choice(np.arange(-rate // 2 + 1, rate // 2), size=N, replace=False)
     if N >= 3:
@@ -141,7 +162,7 @@ def test_direct_parity(cuda_device, gsdr_lib, oracle_mod, monkeypatch, case, imp
     dem.close()
 
 
-def test_direct_fuzz_random_shapes(cuda_device, gsdr_lib, oracle_mod):
+def test_direct_fuzz_random_shapes(cuda_device, gsdr_lib, oracle_mod, engine):
     """Seeded fuzz over (tones, decim, pf_average, buffer_len, rate): shapes nobody
     picked by hand -- prime decimations, single tones, 1-block buffers, F = 5..8
     (generic kernel), tone counts around the 64-lane boundaries."""
@@ -166,7 +187,7 @@ def test_direct_fuzz_random_shapes(cuda_device, gsdr_lib, oracle_mod):
         dem.close()
 
 
-def test_pfb_and_chirp_fuzz_random_shapes(cuda_device, gsdr_lib, oracle_mod):
+def test_pfb_and_chirp_fuzz_random_shapes(cuda_device, gsdr_lib, oracle_mod, engine):
     rng = np.random.default_rng(778)
     for it in range(25):
         nfft = int(rng.choice([2, 3, 8, 10, 17, 50, 64, 100, 333, 1000]))
@@ -212,7 +233,7 @@ def test_pfb_and_chirp_fuzz_random_shapes(cuda_device, gsdr_lib, oracle_mod):
         dem.close()
 
 
-def test_direct_streaming_equals_one_long_buffer(cuda_device, gsdr_lib):
+def test_direct_streaming_equals_one_long_buffer(cuda_device, gsdr_lib, engine):
     """Concatenated per-buffer outputs == one call on the concatenated input."""
     rate, M, F, N = 1_000_000, 100, 4, 9
     rng = np.random.default_rng(5)
@@ -242,7 +263,7 @@ def test_direct_undecimated(cuda_device, gsdr_lib, oracle_mod):
         dem.close()
 
 
-def test_direct_pure_tones_demodulate_to_their_phasors(cuda_device, gsdr_lib):
+def test_direct_pure_tones_demodulate_to_their_phasors(cuda_device, gsdr_lib, engine):
     """Closed form, no oracle: a comb demodulates to a_k e^{i phi_k} (DC gain of h is 1)."""
     from gpu_sdr_amd.source import host_tones
     rate, L, M, F, N = 10_000_000, 100_000, 100, 4, 12
@@ -276,7 +297,7 @@ PFB_CASES = [
 
 
 @pytest.mark.parametrize("case", PFB_CASES, ids=lambda c: "N%d_nfft%d_avg%d_L%d" % (c[0], c[2], c[3], c[4]))
-def test_pfb_parity(cuda_device, gsdr_lib, oracle_mod, case):
+def test_pfb_parity(cuda_device, gsdr_lib, oracle_mod, case, engine):
     N, rate, nfft, avg, L, nbuf = case
     rng = np.random.default_rng(2000 + nfft + avg)
     freq = rng.integers(-rate // 2 + 1, rate // 2, size=N)
@@ -303,7 +324,7 @@ def test_pfb_parity(cuda_device, gsdr_lib, oracle_mod, case):
 
 @pytest.mark.parametrize("nfft,avg,L,nbuf", [(16, 3, 200, 4), (100, 4, 50_000, 3), (1000, 4, 50_123, 3),
                                             (64, 1, 4096, 2)])
-def test_noise_full_spectrum_parity(cuda_device, gsdr_lib, oracle_mod, nfft, avg, L, nbuf):
+def test_noise_full_spectrum_parity(cuda_device, gsdr_lib, oracle_mod, nfft, avg, L, nbuf, engine):
     """NOISE, decim == 0 (ref: process_pfb_spec): every FFT bin, [frame][bin]."""
     import gpu_sdr_amd as g
     rng = np.random.default_rng(4000 + nfft)
@@ -411,15 +432,15 @@ def _full_size_direct(cuda_device, oracle_mod, N, M, nbuf, subset):
     dem.close()
 
 
-def test_c2_256_tones_decim100_full_size(cuda_device, gsdr_lib, oracle_mod):
+def test_c2_256_tones_decim100_full_size(cuda_device, gsdr_lib, oracle_mod, engine):
     _full_size_direct(cuda_device, oracle_mod, N=256, M=100, nbuf=3, subset=12)
 
 
-def test_c3_2048_tones_decim1000_full_size(cuda_device, gsdr_lib, oracle_mod):
+def test_c3_2048_tones_decim1000_full_size(cuda_device, gsdr_lib, oracle_mod, engine):
     _full_size_direct(cuda_device, oracle_mod, N=2048, M=1000, nbuf=3, subset=12)
 
 
-def test_pfb_full_size_1024_tones(cuda_device, gsdr_lib, oracle_mod):
+def test_pfb_full_size_1024_tones(cuda_device, gsdr_lib, oracle_mod, engine):
     """TONES at full buffer size: 1024 tones, the client's typical odd nfft (1230 does
     not divide 1e6: buffer_helper carry every call), oracle on a subset of tones."""
     import torch
@@ -448,7 +469,7 @@ def test_pfb_full_size_1024_tones(cuda_device, gsdr_lib, oracle_mod):
     dem.close()
 
 
-def test_c3_linearity_all_tones(cuda_device, gsdr_lib):
+def test_c3_linearity_all_tones(cuda_device, gsdr_lib, engine):
     """Size-independent property over ALL 2048 tones at full size:
     demod(a + b) == demod(a) + demod(b)."""
     import torch
