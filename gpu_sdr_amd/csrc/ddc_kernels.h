@@ -92,6 +92,7 @@ struct MfmaLaunch {
     const unsigned *fmod;      // [NT32*32]
     const unsigned *maxbits;   // [3] absmax slots
     float2 *out;
+    void *dbg;                 // debug builds of the assembly loop dump registers here
     MfmaShape sh;
 };
 

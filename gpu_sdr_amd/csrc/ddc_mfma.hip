@@ -27,6 +27,13 @@
 #include <vector>
 
 #include "ddc_device.h"
+#include "ddc_mfma_gen.h"
+#ifndef GSDR_MFMA_LDS_UINT4
+#define GSDR_MFMA_LDS_UINT4 2048
+#endif
+#ifndef GSDR_MFMA_ACC_OFF
+#define GSDR_MFMA_ACC_OFF 0u
+#endif
 
 namespace gsdr {
 
@@ -69,6 +76,46 @@ __device__ __forceinline__ Frag make_frag(const float4v xa, const float4v xb, co
 }
 
 }  // namespace
+
+// rot[n,o] = w_n^(idx_base + o*M) / S applied to the accumulators, then the stores.
+template <int TT>
+__device__ __forceinline__ void store_rows(const MfmaLaunch &a, int gt, int n0, int hh, float invS,
+                                           const float16v (&accr)[TT], const float16v (&acci)[TT]) {
+    const MfmaShape &sh = a.sh;
+    const int Np = sh.NT32 * 32;
+    const unsigned long long s_tile = mod_rate(
+        (unsigned long long)sh.idx_base + (unsigned long long)(gt * 32) * sh.m_mod_rate, sh.rate, sh.rate_magic);
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+        const int n = n0 + tt * 32;
+        const unsigned long long ph = mod_rate((unsigned long long)a.fmod[n] * s_tile, sh.rate, sh.rate_magic);
+        double bre, bim;
+        exact_phasor(ph, sh.inv_rate, bre, bim);
+        const float br = (float)bre * invS, bi = (float)bim * invS;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
+            const float2 d = a.dtab[(size_t)row * Np + n];
+            const float rr = br * d.x - bi * d.y, ri = br * d.y + bi * d.x;
+            float2 y;
+            y.x = accr[tt][i] * rr - acci[tt][i] * ri;
+            y.y = accr[tt][i] * ri + acci[tt][i] * rr;
+            const int orow = gt * 32 + row;
+            if (orow < sh.nout && n < sh.N) a.out[(size_t)orow * sh.N + n] = y;
+        }
+    }
+}
+
+// store_rows for the assembly kernel, compiled without packed-FP32 instructions:
+// while another wave of the SIMD runs the assembly loop (an MFMA every few vector
+// instructions), v_pk_*_f32 with a high-half operand select (op_sel:[1,..]) was
+// measured to return wrong values in a quarter-wave now and then
+// (scratch/mfma_probe.py, mfma_diag*.py); the compiler emits that form freely.
+__device__ __attribute__((noinline, target("no-packed-fp32-ops"))) void store_rows_nopk(
+    const MfmaLaunch &a, int gt, int n0, int hh, float invS, const float16v (&accr)[1],
+    const float16v (&acci)[1]) {
+    store_rows<1>(a, gt, n0, hh, invS, accr, acci);
+}
 
 // Workgroup barrier that no LDS access may be scheduled across (asm + memory
 // clobber: the compiler was seen to move ring reads over a plain s_barrier).
@@ -232,29 +279,96 @@ __global__ __launch_bounds__(64 * W, TT == 1 ? 2 : 1) void ddc_mfma_kernel(const
         __builtin_amdgcn_sched_barrier(0);
     }
     if (!active) return;
+    store_rows<TT>(a, gt, n0, hh, invS, accr, acci);
+}
 
-    // ---- rot[n,o] = w_n^(idx_base + o*M) / S, stores ----
-    const unsigned long long s_tile = mod_rate(
-        (unsigned long long)sh.idx_base + (unsigned long long)(gt * 32) * sh.m_mod_rate, sh.rate, sh.rate_magic);
+// The same kernel with its main loop in assembly (tools/gen_ddc_mfma.py): one tone
+// tile per wave, four waves, phasor block 32.  Everything around the loop -- work
+// split, scale, addresses, the final rotation and the stores -- is the C++ above.
+__global__ __launch_bounds__(256, 2) void ddc_mfma_asm_kernel(const MfmaLaunch a) {
+    constexpr int KS = 4, W = 4;
+    // ring (3 slots of 8 KiB) while the loop runs, then the accumulators (4 waves x 8 KiB)
+    __shared__ uint4 lds[GSDR_MFMA_LDS_UINT4];
+    static_assert(sizeof(uint4) * GSDR_MFMA_LDS_UINT4 >= GSDR_MFMA_ASM_RING_BYTES, "ring fits");
+    const MfmaShape &sh = a.sh;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = lane & 31, hh = lane >> 5;
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int gt = (q / sh.ntq) * 8 + xcd;
+    if (gt >= sh.ngt) return;
+    const int tg_raw = (q % sh.ntq) * W + wave;
+    const bool active = tg_raw < sh.ntg;
+    const int tg = active ? tg_raw : sh.ntg - 1;
+
+    const unsigned mb0 = a.maxbits[sh.slot_cur], mb1 = a.maxbits[sh.slot_prev];
+    const unsigned mb = mb0 > mb1 ? mb0 : mb1;
+    int se = 140 - (int)((mb >> 23) & 0xffu);
+    se = se > 100 ? 100 : (se < -100 ? -100 : se);
+    const float S = __uint_as_float((unsigned)(127 + se) << 23);
+    const float invS = __uint_as_float((unsigned)(127 - se) << 23) * sh.unscale;
+
+    // scalar bases + per-lane non-negative byte offsets (global_load ..., voffset, s[base])
+    const int o = gt * 32 + r;
+    const int oc = o < sh.nout ? o : sh.nout - 1;
+    const float2 *xbase;           // sample s of this tile's rows lives at xbase[s + xshift]
+    long long xshift;
+    if (gt == 0) {
+        xbase = a.head;
+        xshift = sh.carry_len;
+    } else if (gt == sh.ngt - 1) {
+        xbase = a.tail;
+        xshift = -sh.tail0;
+    } else {
+        xbase = a.x;
+        xshift = 0;
+    }
+    // this wave converts k-step `wave` of every block: 8 samples = 64 bytes further on
+    const unsigned xo = (unsigned)((((long long)(oc + sh.woff) * sh.M + xshift) + 4 * hh + 8 * wave) * 8);
+    const unsigned to = (unsigned)((4 * hh + 8 * wave) * 4);
+    const int Np = sh.NT32 * 32;
+    const int n0 = tg * 32 + r;
+    const unsigned po = (unsigned)n0 * 8u;
+    const unsigned bo = (unsigned)tg * (KS * 4 * 1024u) + (unsigned)lane * 16u;
+    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char *)lds;
+    const unsigned lane16 = lds_base + (unsigned)lane * 16u;
+    const unsigned wr16 = lane16 + (unsigned)wave * 2048u;
+    const unsigned accaddr = lds_base + GSDR_MFMA_ACC_OFF + (unsigned)wave * 8192u + (unsigned)lane * 16u;
+    const unsigned long long xb = (unsigned long long)xbase, tpb = (unsigned long long)a.taps,
+                             ppb = (unsigned long long)a.ptab, bfb = (unsigned long long)a.bfrag;
+    const int nhi = (sh.nk8 + KS - 1) / KS;
+#ifdef GSDR_MFMA_ASM_DEBUG
+    const unsigned long long dbgb = (unsigned long long)a.dbg;
+    const unsigned dbgo = (unsigned)((blockIdx.x * 4 + wave) * 8192 + lane * 16);
+#endif
+    asm volatile(GSDR_MFMA_ASM_TEXT
+                 :
+                 :
+#ifdef GSDR_MFMA_ASM_DEBUG
+                   [dbgo] "v"(dbgo), [dbg_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)dbgb)),
+                   [dbg_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(dbgb >> 32))),
+#endif
+                   [xo] "v"(xo), [to] "v"(to), [po] "v"(po), [bo] "v"(bo), [lane16] "v"(lane16),
+                   [wr16] "v"(wr16), [accaddr] "v"(accaddr), [xb_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)xb)),
+                   [xb_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(xb >> 32))), [tp_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)tpb)),
+                   [tp_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(tpb >> 32))), [pp_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)ppb)),
+                   [pp_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(ppb >> 32))), [bf_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)bfb)),
+                   [bf_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(bfb >> 32))), [pstride] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)Np * 8u)), [nhi] "s"(__builtin_amdgcn_readfirstlane(nhi)),
+                   [scale] "s"(__builtin_amdgcn_readfirstlane((int)__float_as_uint(S)))
+                 : GSDR_MFMA_ASM_CLOBBERS);
+    if (!active) return;
+    float16v accr[1], acci[1];
+    const float4v *acc = reinterpret_cast<const float4v *>(lds) + GSDR_MFMA_ACC_OFF / 16 + wave * 512 + lane;
 #pragma unroll
-    for (int tt = 0; tt < TT; ++tt) {
-        const int n = n0 + tt * 32;
-        const unsigned long long ph = mod_rate((unsigned long long)a.fmod[n] * s_tile, sh.rate, sh.rate_magic);
-        double bre, bim;
-        exact_phasor(ph, sh.inv_rate, bre, bim);
-        const float br = (float)bre * invS, bi = (float)bim * invS;
+    for (int qd = 0; qd < 4; ++qd) {
+        const float4v vr = acc[qd * 64], vi = acc[(qd + 4) * 64];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
-            const float2 d = a.dtab[(size_t)row * Np + n];
-            const float rr = br * d.x - bi * d.y, ri = br * d.y + bi * d.x;
-            float2 y;
-            y.x = accr[tt][i] * rr - acci[tt][i] * ri;
-            y.y = accr[tt][i] * ri + acci[tt][i] * rr;
-            const int orow = gt * 32 + row;
-            if (orow < sh.nout && n < sh.N) a.out[(size_t)orow * sh.N + n] = y;
+        for (int j = 0; j < 4; ++j) {
+            accr[0][qd * 4 + j] = vr[j];
+            acci[0][qd * 4 + j] = vi[j];
         }
     }
+    store_rows_nopk(a, gt, n0, hh, invS, accr, acci);
 }
 
 // One pass over the new buffer x[0..n):
@@ -441,6 +555,14 @@ hipError_t launch_ddc_mfma(int TT, int PK, int W, int sgb, const MfmaLaunch &a, 
     if (a.x != a.tail && sh.ngt > 2 && (long long)(32 * (sh.ngt - 1) - 1 + sh.woff) * sh.M + reach > sh.nx)
         return hipErrorInvalidValue;
     if (sh.ngt > 1 && (long long)(32 * (sh.ngt - 1) + sh.woff) * sh.M < sh.tail0) return hipErrorInvalidValue;
+    if (sgb == 9) {   // assembly main loop: one tone tile per wave, four waves, block 32
+        if (TT != 1 || PK != 32 || W != 4) return hipErrorInvalidValue;
+        const int gt8 = (sh.ngt + 7) / 8;
+        const long long grid = (long long)gt8 * 8 * sh.ntq;
+        if (grid < 1 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(ddc_mfma_asm_kernel, dim3((unsigned)grid), dim3(256), 0, st, a);
+        return hipGetLastError();
+    }
     if (TT == 2 && PK == 32) return launch_tp<2, 32>(W, sgb, a, st);
     if (TT == 1 && PK == 32) return launch_tp<1, 32>(W, sgb, a, st);
     if (TT == 2 && PK == 16) return launch_tp<2, 16>(W, sgb, a, st);

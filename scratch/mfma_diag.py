@@ -33,5 +33,14 @@ for c in range(4):
         print("  bad fraction per row %% 32:", [round(float(pr[k::32].mean()), 2) for k in range(32)])
         print("  bad fraction per row tile (first 12, last 4):", [round(float(pr[k*32:(k+1)*32].mean()), 2) for k in list(range(12)) + list(range(len(pr)//32 - 4, len(pr)//32))])
         rows = bad[:, 0].cpu().numpy(); cols = bad[:, 1].cpu().numpy()
+        if c == 1:
+            for o in np.unique(rows)[:5]:
+                cc = cols[rows == o]
+                print("  row", o, "row%32", o % 32, "tones", cc.min(), "..", cc.max(), "n", len(cc))
+                print("    flat:", ya[o, cc[:4]].cpu().numpy())
+                print("    mfma:", yb[o, cc[:4]].cpu().numpy())
+                print("    mfma/flat:", (yb[o, cc[:4]] / ya[o, cc[:4]]).cpu().numpy())
+                if o + 1 < ya.shape[0]:
+                    print("    flat next row:", ya[o + 1, cc[:4]].cpu().numpy())
         print("  rows", np.unique(rows)[:40], "... tiles", np.unique(rows // 32)[:40])
         print("  tones", np.unique(cols)[:64])
