@@ -341,7 +341,10 @@ int setup_mfma(gsdr_demod *h, bool direct, const std::vector<long long> &tone) {
     if (h->mf_sgb != 0 && h->mf_sgb != 2 && h->mf_sgb != 3) h->mf_sgb = 4;
     // the assembly main loop (ddc_mfma_asm_kernel) exists for the default shape only;
     // GSDR_MFMA_ASM=0 keeps the compiler-scheduled kernel (A/B runs, tests)
-    if (env_int("GSDR_MFMA_ASM", 1) != 0 && h->mf_TT == 1 && h->mf_PK == 32 && h->mf_W == 4) h->mf_sgb = 9;
+    // (and for windows whose scaled taps fit its 40 KiB LDS table: 10240 - 128 taps)
+    if (env_int("GSDR_MFMA_ASM", 1) != 0 && h->mf_TT == 1 && h->mf_PK == 32 && h->mf_W == 4 &&
+        ((M * F + 31) / 32) * 32 + 128 <= 10240)
+        h->mf_sgb = 9;
     if (h->mf_W > h->mf_PK / 8) h->mf_W = h->mf_PK / 8;
     gsdr::MfmaPlan pl{};
     pl.TT = h->mf_TT;

@@ -1,91 +1,82 @@
 #!/usr/bin/env python3
-"""Generates gpu_sdr_amd/csrc/ddc_mfma_gen.h: the software-pipelined main loop of
-ddc_mfma_asm_kernel (gfx950) as one inline-asm block with a fixed register map.
+"""Generates gpu_sdr_amd/csrc/ddc_mfma_gen.h: the main loop of ddc_mfma_asm_kernel
+(gfx950) as one inline-asm block with a fixed register map.
 
-Why assembly: the loop's correctness depends on physical register reuse
-distances the compiler does not know about (an LDS return landing in a register
-that a just-issued MFMA still reads as operand corrupts rows 16..31 of that
-MFMA, see ddc_mfma.hip), and its speed on an exact MFMA/VALU interleave.
+Why assembly: the loop's correctness depends on register reuse distances and
+operand forms the compiler does not know about (see "Rules" below, all measured
+on MI355X with scratch/mfma_probe.py and scratch/mfma_diag*.py), and its speed
+on an exact MFMA/VALU interleave.
 
-One iteration = one phasor block of 32 samples = 4 k-steps x 6 MFMAs
-(v_mfma_f32_32x32x16_f16: Cr/Ci x {hi*Bhi, hi*Blo, lo*Bhi}).  In the shadow of
-block b's MFMAs the wave
-  * reads the A operand of the next k-step from the LDS ring (4 operand buffers:
-    a buffer is overwritten 12 MFMAs after its last use),
-  * applies P*C of block b-1 on the VALU (C alternates between two register
-    sets, hence the 2x unroll),
-  * converts its k-step of block b+2 (x * taps * S -> fp16 hi/lo) into ring
-    slot (b+2)%3 and loads its k-step of block b+3.
-One s_barrier per iteration.
+Work of one wave: 32 output rows x 32 tones; every phasor block of 32 samples is
+4 k-steps x 6 MFMAs (v_mfma_f32_32x32x16_f16: Cr/Ci x {hi*Bhi, hi*Blo, lo*Bhi}).
+No LDS ring and no barrier in the loop: each wave converts its own A operand (the
+four waves of a workgroup redo the same 20 VALU instructions per k-step, which fit
+in the MFMAs' shadow, and share the input through the L1).  In the shadow of
+k-step t the wave
+  * converts k-step t+1: x * (taps*S) -> fp16 hi/lo, registers only,
+  * issues the loads of k-step t+5 (x, global) and t+3 (taps*S, the workgroup's
+    LDS table),
+  * applies a quarter of P*C of the previous block on the VALU (C alternates
+    between two register sets, hence the 2x unroll).
+All of that is plain (non-packed) FP32: tools/ubench_mfma.hip measures that
+v_pk_fma_f32 / v_pk_mul_f32 do not overlap with the f16 MFMA at all (+10 cycles
+each), while v_fma_f32, v_mul_f32, v_cvt_pk_f16_f32 and v_fma_mix_f32 nearly
+vanish in its shadow at two waves per SIMD (6 per MFMA: +7 %).
 
-s_waitcnt values come from a model of the two counters (class Counters), not
-from hand counting.
+Rules this file keeps (each one cost a debugging session):
+  R1  A register that an MFMA reads as A/B operand is not rewritten before twelve
+      further MFMAs have been issued (four operand buffers).  With less distance
+      rows 16..31 of the MFMA came out computed from the new contents.
+  R2  Address, data and scalar-base registers of a memory instruction stay unchanged
+      for two k-steps after it was issued: with two workgroups on a CU they are read
+      late (registers rewritten ~4 MFMAs later gave half of the lanes the new address).
+  R3  No v_pk_*_f32 with a high-half broadcast (op_sel:[1,..]): it returned wrong
+      values in lanes 48..63 now and then while another wave of the SIMD ran this
+      loop.  The loop has no packed FP32 at all (see above); the C++ epilogue of the
+      kernel is compiled without packed FP32 for this reason.
+  R4  s_waitcnt values come from a model of the counters (class Counters).
 
     python3 tools/gen_ddc_mfma.py > gpu_sdr_amd/csrc/ddc_mfma_gen.h
 """
+
 import os
-import sys
+
+# timing-only builds (wrong results): GEN_ABLATE=rot,conv,loads,mfma drops that work from the loop
+ABLATE = set(filter(None, os.environ.get("GEN_ABLATE", "").split(",")))
 
 KS = 4                     # k-steps per block (PK = 32)
-SLOT = KS * 2 * 1024       # bytes of one ring slot
 
-# ---- register map (TT = 1) -------------------------------------------------
-VB = 16                    # v0..v15 stay with the compiler
-# The MFMA results (C sets A and B) live in AGPRs a[64:127]: with VGPR destinations,
-# single result registers of a quarter-wave were found stale by the VALU pass a block
-# later, now and then, when two waves shared the SIMD.  The VALU reads them through
-# v_accvgpr_read_b32 into the T registers.
-CA = (64, 80)              # a[64:79] re, a[80:95] im
-CB = (96, 112)
-ACC = (VB + 0, VB + 16)    # accumulators re v[16:31], im v[32:47]
-F0 = VB + 32               # operand buffers: step s hi v[F0+8s:+3], lo v[F0+8s+4:+3]
-XA, XB, HV = VB + 64, VB + 68, VB + 72
-HI4, LO4 = VB + 76, VB + 80
-VB2 = VB - 64              # keeps the offsets below as they were
-# Broadcast operands (rotation factors, scaled taps) live in the LOW half of an even
-# register pair and are read with op_sel_hi:[0,..]: reading the high half for both
-# results (op_sel:[1,..]) returned wrong values in lanes 48..63 now and then when a
-# second wave shared the SIMD (scratch/mfma_probe.py).  The odd partner of such a
-# pair is read and ignored, so it can hold an unrelated scalar.
-PB = (VB2 + 148, VB2 + 150)  # (Pr, Pi) of C set B: v172, v174
-V_SC = VB2 + 149            # v173 = S
-PA = (VB2 + 152, VB2 + 154)  # v176, v178
-HSP = [VB2 + 156, VB2 + 158, VB2 + 160, VB2 + 162]   # scaled taps: v180, v182, v184, v186
-# ring addresses, one set per iteration parity: an LDS instruction must find its
-# address (and data) registers unchanged until it has completed -- measured: with
-# two workgroups per CU, registers rewritten ~4 MFMAs after the ds_read/ds_write
-# that used them gave the upper half-rows (lanes 16..31, 48..63) the new address
-ADDR = {"A": (VB2 + 157, VB2 + 159, VB2 + 161), "B": (VB2 + 163, VB2 + 165, VB2 + 167)}
-TMP = VB2 + 168           # 8 registers: v_accvgpr_read targets of the rotation
-V_LAST = VB2 + 175
+# ---- register map ------------------------------------------------------------
+VB = 12                    # v0..v11 stay with the compiler
+CA = (VB + 0, VB + 16)     # C set A: re, im (16 registers each)
+CB = (VB + 32, VB + 48)    # C set B
+ACC = (VB + 64, VB + 80)   # accumulators re, im
+F0 = VB + 96               # operand buffers: k-step s hi v[F0+8s:+3], lo v[F0+8s+4:+3]
+X0 = VB + 128              # input buffers: k-step t in v[X0+8(t%4):+7]
+H0 = VB + 160              # scaled taps of a k-step: parity p: v[H0+4p:+3]
+PA = (VB + 168, VB + 169)  # (Pr, Pi) of C set A
+PB = (VB + 170, VB + 171)
+V_TB = [VB + 172, VB + 173, VB + 174, VB + 175]   # taps table address of k-step position q
+V_LAST = VB + 175
 NVGPR_CLOBBER = list(range(VB, V_LAST + 1))
-NAGPR = 128
+NAGPR = 64                 # phasor-table images
 
 # private SGPRs
-# scalar bases of the global loads, one set per iteration parity (same reason as
-# the ring address registers: never rewrite what a queued memory instruction reads)
-SB = {"A": dict(x=36, t=38, p=40), "B": dict(x=60, t=62, p=64)}
-S_NLEFT, S_K, S_NHI1 = 42, 43, 44
-S_RD, S_RDN, S_WR = 45, 46, 47
-S_SC = 48      # s[48:49] = (S, S)
-S_T0, S_T1 = 50, 51
-S_XB = 52      # s[52:53] x base, block 0
-S_TB = 54      # s[54:55] taps base, block 0
-S_BF = 56      # s[56:57] phasor-table images
-S_PSTRIDE = 58
-SGPR_CLOBBER = list(range(36, 76))
+S_XB = 36                  # s[36:37] x base, k-step 0
+S_XS = [38, 40, 42, 44]    # x base of the next load of k-step position q (R2: one each)
+S_P = {"A": 46, "B": 48}   # P row pointer, one per parity (R2)
+S_NLEFT, S_B, S_KMAX = 50, 51, 52
+S_T0 = 53
+S_PSTRIDE = 55
+S_BF = [56, 58, 60, 62]    # phasor-table image bases
+SGPR_CLOBBER = list(range(36, 64))
 
 
 def vr(base, n=1):
     return f"v{base}" if n == 1 else f"v[{base}:{base + n - 1}]"
 
 
-BV = int(os.environ.get("GEN_B_VGPR", "0"))   # experiment: phasor images in v[192:255] instead of AGPRs
-
-
 def ar(base, n=4):
-    if BV:
-        return f"v[{192 + base}:{192 + base + n - 1}]"
     return f"a[{base}:{base + n - 1}]"
 
 
@@ -113,8 +104,6 @@ class Counters:
         i = len(lst) - 1 - lst[::-1].index(tag)
         n = len(lst) - 1 - i
         self.out.append(f"s_waitcnt {name}({n})")
-        if name == "vmcnt" and os.environ.get("GEN_NOP_AFTER_VM"):
-            self.out.append("s_nop 15")
         del lst[: i + 1]
 
     def need_lgkm(self, tag):
@@ -123,91 +112,80 @@ class Counters:
     def need_vm(self, tag):
         self._need(self.vm, tag, "vmcnt")
 
-    def drain_lgkm(self):
-        self.out.append("s_waitcnt lgkmcnt(0)")
-        self.lgkm = []
-
 
 def rotate_ops(cset, p):
-    """acc += P * C for all 16 register pairs.  p = (Pr, Pi): each in the low half of
-    its own pair, broadcast with op_sel_hi:[0,1,1].  Per register pair: four
-    v_accvgpr_read_b32 (Cr, Ci) and four v_pk_fma_f32; the reads of pair i+1 are
-    issued before the arithmetic of pair i (two T sets)."""
+    """acc += P * C: 64 v_fma_f32 in four sweeps (an accumulator is read again 16
+    instructions after it was written).  p = (Pr, Pi)."""
     cr, ci = cset
-    pr, pi = vr(p[0], 2), vr(p[1], 2)
+    pr, pi = vr(p[0]), vr(p[1])
     ops = []
-
-    def reads(i, t):
-        return [f"v_accvgpr_read_b32 {vr(t)}, a{cr + i}", f"v_accvgpr_read_b32 {vr(t + 1)}, a{cr + i + 1}",
-                f"v_accvgpr_read_b32 {vr(t + 2)}, a{ci + i}", f"v_accvgpr_read_b32 {vr(t + 3)}, a{ci + i + 1}"]
-
-    def arith(i, t):
-        a_r, a_i = vr(ACC[0] + i, 2), vr(ACC[1] + i, 2)
-        c_r, c_i = vr(t, 2), vr(t + 2, 2)
-        return [f"v_pk_fma_f32 {a_r}, {pr}, {c_r}, {a_r} op_sel_hi:[0,1,1]",
-                f"v_pk_fma_f32 {a_i}, {pr}, {c_i}, {a_i} op_sel_hi:[0,1,1]",
-                f"v_pk_fma_f32 {a_r}, {pi}, {c_i}, {a_r} op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]",
-                f"v_pk_fma_f32 {a_i}, {pi}, {c_r}, {a_i} op_sel_hi:[0,1,1]"]
-
-    pairs = list(range(0, 16, 2))
-    ops += reads(pairs[0], TMP)
-    for n, i in enumerate(pairs):
-        t = TMP + 4 * (n & 1)
-        if n + 1 < len(pairs):
-            ops += reads(pairs[n + 1], TMP + 4 * ((n + 1) & 1))
-        ops += arith(i, t)
+    for term in range(4):
+        for i in range(16):
+            a_r, a_i = vr(ACC[0] + i), vr(ACC[1] + i)
+            c_r, c_i = vr(cr + i), vr(ci + i)
+            if term == 0:
+                ops.append(f"v_fma_f32 {a_r}, {pr}, {c_r}, {a_r}")
+            elif term == 1:
+                ops.append(f"v_fma_f32 {a_i}, {pr}, {c_i}, {a_i}")
+            elif term == 2:
+                ops.append(f"v_fma_f32 {a_r}, -{pi}, {c_i}, {a_r}")
+            else:
+                ops.append(f"v_fma_f32 {a_i}, {pi}, {c_r}, {a_i}")
     return ops
 
 
-def produce_ops():
-    """x (4 complex samples in XA, XB) * taps (HV) * S -> fp16 hi (HI4) and lo (LO4).
-    Returns VALU ops; the two ds_write follow separately.
-
-    Every scaled tap sits alone in the LOW half of its own register pair and is
-    broadcast from there (op_sel_hi:[1,0]).  The first version packed two taps per
-    pair (v_pk_mul_f32 by (S,S)) and read the odd ones from the HIGH half
-    (op_sel:[0,1]): with a second wave on the SIMD, lanes 48..63 now and then got
-    0 for exactly those products (scratch/mfma_probe.py dumps the registers)."""
+def convert_ops(xb, hp, buf):
+    """x (4 complex samples in X buffer xb) * scaled taps (H[hp]) -> fp16 hi/lo in operand
+    buffer `buf`.  24 VALU instructions, x is consumed in place."""
+    xa = X0 + 8 * xb
+    xs = [xa, xa + 2, xa + 4, xa + 6]
+    h = H0 + 4 * hp
+    fh, fl = F0 + 8 * buf, F0 + 8 * buf + 4
     ops = []
     for j in range(4):
-        ops.append(f"v_mul_f32 {vr(HSP[j])}, {vr(HV + j)}, {vr(V_SC)}")
-    xs = [XA, XA + 2, XB, XB + 2]
+        ops.append(f"v_mul_f32 {vr(xs[j])}, {vr(xs[j])}, {vr(h + j)}")
+        ops.append(f"v_mul_f32 {vr(xs[j] + 1)}, {vr(xs[j] + 1)}, {vr(h + j)}")
     for j in range(4):
-        ops.append(f"v_pk_mul_f32 {vr(xs[j], 2)}, {vr(xs[j], 2)}, {vr(HSP[j], 2)} op_sel_hi:[1,0]")
+        ops.append(f"v_cvt_pk_f16_f32 {vr(fh + j)}, {vr(xs[j])}, {vr(xs[j] + 1)}")
+    for j in range(4):                       # residual v - float(hi), in place
+        ops.append(f"v_fma_mix_f32 {vr(xs[j])}, {vr(xs[j])}, 1.0, -{vr(fh + j)} op_sel_hi:[0,0,1]")
+        ops.append(f"v_fma_mix_f32 {vr(xs[j] + 1)}, {vr(xs[j] + 1)}, 1.0, -{vr(fh + j)} op_sel:[0,0,1] op_sel_hi:[0,0,1]")
     for j in range(4):
-        ops.append(f"v_cvt_pk_f16_f32 {vr(HI4 + j)}, {vr(xs[j])}, {vr(xs[j] + 1)}")
-    # residual r = v - float(hi) (in place), then lo = fp16(r)
-    for j in range(4):
-        ops.append(f"v_fma_mix_f32 {vr(xs[j])}, {vr(xs[j])}, 1.0, -{vr(HI4 + j)} op_sel_hi:[0,0,1]")
-        ops.append(f"v_fma_mix_f32 {vr(xs[j] + 1)}, {vr(xs[j] + 1)}, 1.0, -{vr(HI4 + j)} op_sel:[0,0,1] op_sel_hi:[0,0,1]")
-    for j in range(4):
-        ops.append(f"v_cvt_pk_f16_f32 {vr(LO4 + j)}, {vr(xs[j])}, {vr(xs[j] + 1)}")
+        ops.append(f"v_cvt_pk_f16_f32 {vr(fl + j)}, {vr(xs[j])}, {vr(xs[j] + 1)}")
     return ops
 
 
-def gload_ops(cnt, out, par):
-    S_X, S_T = SB[par]["x"], SB[par]["t"]
-    out.append(f"global_load_dwordx4 {vr(HV, 4)}, %[to], s[{S_T}:{S_T + 1}]")
-    cnt.issue_vm("hv")
-    out.append(f"global_load_dwordx4 {vr(XA, 4)}, %[xo], s[{S_X}:{S_X + 1}]")
-    cnt.issue_vm("xa")
-    out.append(f"global_load_dwordx4 {vr(XB, 4)}, %[xo], s[{S_X}:{S_X + 1}] offset:16")
-    cnt.issue_vm("xb")
+def load_x(cnt, out, q, xb):
+    """x of the next k-step at position q of its block, into X buffer xb."""
+    xa = X0 + 8 * xb
+    out.append(f"global_load_dwordx4 {vr(xa, 4)}, %[xo], s[{S_XS[q]}:{S_XS[q] + 1}]")
+    cnt.issue_vm(f"xa{xb}")
+    out.append(f"global_load_dwordx4 {vr(xa + 4, 4)}, %[xo], s[{S_XS[q]}:{S_XS[q] + 1}] offset:16")
+    cnt.issue_vm(f"xb{xb}")
 
 
-def advance_load_pointers(par):
-    """SALU: pointers (parity set `par`) of block min(S_K, nhi-1), then S_K += 1."""
-    S_X, S_T = SB[par]["x"], SB[par]["t"]
+def load_h(cnt, out, q, hp):
+    """scaled taps of the next k-step at position q, into H[hp]."""
+    out.append(f"ds_read_b128 {vr(H0 + 4 * hp, 4)}, {vr(V_TB[q])}")
+    cnt.issue_lgkm(f"h{hp}")
+
+
+def advance_x(q, add):
+    """x base of position q for block S_B + add; the k-step index is clamped to the last
+    one (loads past the window: valid addresses, zero taps)."""
     return [
-        f"s_min_u32 s{S_T0}, s{S_K}, s{S_NHI1}",
-        f"s_lshl_b32 s{S_T1}, s{S_T0}, 8",
-        f"s_add_u32 s{S_X}, s{S_XB}, s{S_T1}",
-        f"s_addc_u32 s{S_X + 1}, s{S_XB + 1}, 0",
-        f"s_lshl_b32 s{S_T1}, s{S_T0}, 7",
-        f"s_add_u32 s{S_T}, s{S_TB}, s{S_T1}",
-        f"s_addc_u32 s{S_T + 1}, s{S_TB + 1}, 0",
-        f"s_add_u32 s{S_K}, s{S_K}, 1",
+        f"s_add_u32 s{S_T0}, s{S_B}, {add}",
+        f"s_lshl_b32 s{S_T0}, s{S_T0}, 2",
+        f"s_add_u32 s{S_T0}, s{S_T0}, {q}",
+        f"s_min_u32 s{S_T0}, s{S_T0}, s{S_KMAX}",
+        f"s_lshl_b32 s{S_T0}, s{S_T0}, 6",
+        f"s_add_u32 s{S_XS[q]}, s{S_XB}, s{S_T0}",
+        f"s_addc_u32 s{S_XS[q] + 1}, s{S_XB + 1}, 0",
     ]
+
+
+def advance_h(q):
+    return [f"v_add_u32 {vr(V_TB[q])}, 128, {vr(V_TB[q])}"]
 
 
 def mfma(cset, ks, m):
@@ -217,246 +195,169 @@ def mfma(cset, ks, m):
     c = m & 1
     sp = 1 if m in (2, 3) else 0
     dst = cr if c == 0 else ci
-    d = f"a[{dst}:{dst + 15}]"
-    src_c = "0" if (ks == 0 and m < 2) else d
-    return f"v_mfma_f32_32x32x16_f16 {d}, {vr(a, 4)}, {bfrag(ks, c, sp)}, {src_c}"
+    src_c = "0" if (ks == 0 and m < 2) else vr(dst, 16)
+    return f"v_mfma_f32_32x32x16_f16 {vr(dst, 16)}, {vr(a, 4)}, {bfrag(ks, c, sp)}, {src_c}"
 
 
 def iteration(cnt, out, cur, prev, p_cur, p_prev, label):
-    """One block.  cur/prev: C sets; p_cur/p_prev: P registers."""
-    out.append(f"; ---- block iteration, C set {label}")
-    rot = rotate_ops(prev, p_prev)
-    prod = produce_ops()
+    """One block = 4 k-steps.  In k-step s (global index t):
+       convert k-step t+1 (X[(s+1)%4], H[(s+1)%2] -> operand buffer (s+1)%4);
+       x of k-step t+5 -> X[(s+1)%4] (position (s+1)%4 of the next block, or of the one
+       after for s == 3); taps of k-step t+3 -> H[(s+1)%2] (position (s+3)%4);
+       a quarter of the previous block's P*C;
+       bases: the x base used two k-steps ago and the taps address used two k-steps
+       ago move one block on (R2)."""
     other = "B" if label == "A" else "A"
-    salu = advance_load_pointers(other)          # for the next iteration's loads
-    S_P, N_P = SB[label]["p"], SB[other]["p"]
-    gaps = {g: [] for g in range(24)}
-
-    def read_step(g, slot_reg, ks_src, buf):
-        fh, fl = F0 + 8 * buf, F0 + 8 * buf + 4
-        gaps[g].append(("lds", f"ds_read_b128 {vr(fh, 4)}, {vr(slot_reg)} offset:{ks_src * 2048}", f"f{buf}h"))
-        gaps[g].append(("lds", f"ds_read_b128 {vr(fl, 4)}, {vr(slot_reg)} offset:{ks_src * 2048 + 1024}", f"f{buf}l"))
-
-    V_RD, V_RDN, V_WR = ADDR[label]
-    N_RD, N_RDN, N_WR = ADDR["B" if label == "A" else "A"]
-    # operand reads: step ks+1 at the first MFMA of step ks; next block's step 0 at step 3
-    read_step(0, V_RD, 1, 1)
-    read_step(6, V_RD, 2, 2)
-    read_step(12, V_RD, 3, 3)
-    read_step(18, V_RDN, 0, 0)
-    # P of this block (used next iteration), pointer advance afterwards
-    gaps[0].append(("vm", f"global_load_dword {vr(p_cur[0])}, %[po], s[{S_P}:{S_P + 1}]", "pr" + label))
-    gaps[0].append(("vm", f"global_load_dword {vr(p_cur[1])}, %[po], s[{S_P}:{S_P + 1}] offset:4", "p" + label))
-    gaps[1].append(("salu", f"s_add_u32 s{N_P}, s{S_P}, s{S_PSTRIDE}", None))
-    gaps[1].append(("salu", f"s_addc_u32 s{N_P + 1}, s{S_P + 1}, 0", None))
-    for i, s in enumerate(salu):
-        gaps[1 + i // 3].append(("salu", s, None))
-    # P*C of the previous block: gaps 3..9 (3 each) and 18..23 (2 each)
-    ri = 0
-    for g in list(range(3, 10)):
-        for _ in range(5):
-            gaps[g].append(("rot", rot[ri], None))
-            ri += 1
-    per = -(-(len(rot) - ri) // 6)
-    for g in range(18, 24):
-        for _ in range(per):
-            if ri < len(rot):
-                gaps[g].append(("rot", rot[ri], None))
-                ri += 1
-    assert ri == len(rot), ri
-    # conversion of block b+2: gaps 10..17
-    pi = 0
-    for g in range(10, 18):
-        for _ in range(3):
-            if pi < len(prod):
-                gaps[g].append(("prod", prod[pi], None))
-                pi += 1
-    assert pi == len(prod), (pi, len(prod))
-
-    if os.environ.get("GEN_NOP_BEFORE_WRITE"):
-        gaps[17].append(("salu", "s_nop 7", None))
-    gaps[17].append(("ldsw", f"ds_write_b128 {vr(V_WR)}, {vr(HI4, 4)}", "wh"))
-    gaps[17].append(("ldsw", f"ds_write_b128 {vr(V_WR)}, {vr(LO4, 4)} offset:1024", "wl"))
-    # loads of block b+3 once the conversion has read XA/XB/HV
-    gaps[19].append(("gload", None, None))
-    # ring slot rotation and addresses of the next iteration (all ring accesses issued by gap 18)
-    gaps[20].append(("salu", f"s_mov_b32 s{S_T0}, s{S_RD}", None))
-    gaps[20].append(("salu", f"s_mov_b32 s{S_RD}, s{S_RDN}", None))
-    gaps[20].append(("salu", f"s_mov_b32 s{S_RDN}, s{S_WR}", None))
-    gaps[20].append(("salu", f"s_mov_b32 s{S_WR}, s{S_T0}", None))
-    gaps[21].append(("addr", f"v_add_u32 {vr(N_RD)}, s{S_RD}, %[lane16]", None))
-    gaps[22].append(("addr", f"v_add_u32 {vr(N_RDN)}, s{S_RDN}, %[lane16]", None))
-    gaps[22].append(("addr", f"v_add_u32 {vr(N_WR)}, s{S_WR}, %[wr16]", None))
-
+    rot = rotate_ops(prev, p_prev)
     first_rot = True
-    first_prod = True
-    for g in range(24):
-        ks, m = divmod(g, 6)
-        if m == 0:
-            cnt.need_lgkm(f"f{ks}h")
-        if m == 4:
-            cnt.need_lgkm(f"f{ks}l")
-        out.append(mfma(cur, ks, m))
-        for kind, text, tag in gaps[g]:
-            if kind == "lds" or kind == "ldsw":
-                out.append(text)
-                cnt.issue_lgkm(tag)
-            elif kind == "vm":
-                out.append(text)
-                cnt.issue_vm(tag)
-            elif kind == "rot":
-                if first_rot:
-                    cnt.need_vm("pB" if label == "A" else "pA")
-                    first_rot = False
-                out.append(text)
-            elif kind == "prod":
-                if first_prod:
-                    if os.environ.get("GEN_VM0"):
-                        out.append("s_waitcnt vmcnt(0)")
-                        cnt.vm = []
-                    else:
-                        cnt.need_vm("xb")
-                    first_prod = False
-                out.append(text)
-            elif kind == "gload":
-                gload_ops(cnt, out, label)
-            else:
-                out.append(text)
-    cnt.drain_lgkm()
-    out.append("s_barrier")
+    for s in range(4):
+        xb, hp = (s + 1) & 3, (s + 1) & 1
+        conv = convert_ops(xb, hp, (s + 1) & 3)
+        fill = [("conv", i) for i in range(len(conv))]
+        fill.append(("loadx", (s + 1) & 3, xb))
+        fill.append(("loadh", (s + 3) & 3, hp))
+        fill += [("rot", r) for r in rot[16 * s: 16 * s + 16]]
+        # x base of position q is used at k-step (q-1)%4 and moved at (q+1)%4;
+        # taps address of position q is used at k-step (q+1)%4 and moved at (q+3)%4
+        qx = (s - 1) & 3
+        salu = advance_x(qx, 2 if qx in (1, 2, 0) else 1) + advance_h((s + 1) & 3)
+        if s == 0:
+            salu += [f"s_add_u32 s{S_P[other]}, s{S_P[label]}, s{S_PSTRIDE}",
+                     f"s_addc_u32 s{S_P[other] + 1}, s{S_P[label] + 1}, 0"]
+        per_gap = -(-len(fill) // 6)
+        pos = 0
+        for m in range(6):
+            if "mfma" not in ABLATE:
+                out.append(mfma(cur, s, m))
+            if m == 0 and s == 0:
+                out.append(f"global_load_dword {vr(p_cur[0])}, %[po], s[{S_P[label]}:{S_P[label] + 1}]")
+                cnt.issue_vm("pr" + label)
+                out.append(f"global_load_dword {vr(p_cur[1])}, %[po], s[{S_P[label]}:{S_P[label] + 1}] offset:4")
+                cnt.issue_vm("p" + label)
+            if m == 1:
+                out.extend(salu)
+            for item in fill[pos: pos + per_gap]:
+                if item[0] == "conv":
+                    if item[1] == 0 and "loads" not in ABLATE:
+                        cnt.need_lgkm(f"h{hp}")
+                        cnt.need_vm(f"xb{xb}")
+                    if "conv" not in ABLATE:
+                        out.append(conv[item[1]])
+                elif item[0] == "loadx":
+                    if "loads" not in ABLATE:
+                        load_x(cnt, out, item[1], item[2])
+                elif item[0] == "loadh":
+                    if "loads" not in ABLATE:
+                        load_h(cnt, out, item[1], item[2])
+                else:
+                    if first_rot:
+                        cnt.need_vm("p" + other)
+                        first_rot = False
+                    if "rot" not in ABLATE:
+                        out.append(item[1])
+            pos += per_gap
+        assert pos >= len(fill)
+    out.append(f"s_add_u32 s{S_B}, s{S_B}, 1")
 
 
-DEBUG = bool(os.environ.get("GEN_DEBUG"))
-S_DBG = 72   # s[72:73], s[74:75] = +4096
-
-
-def dbg_store(out, rec, reg):
-    """debug build: record `rec` (1 KiB per wave) <- v[reg:reg+3]"""
-    if not DEBUG:
-        return
-    b = S_DBG if rec < 4 else S_DBG + 2
-    out.append(f"global_store_dwordx4 %[dbgo], {vr(reg, 4)}, s[{b}:{b + 1}] offset:{(rec % 4) * 1024}")
-    out.append("s_waitcnt vmcnt(0)")
+def body(cnt, out):
+    o = out.append
+    o("1:")
+    iteration(cnt, out, CA, CB, PA, PB, "A")
+    o(f"s_sub_u32 s{S_NLEFT}, s{S_NLEFT}, 1")
+    o(f"s_cmp_eq_u32 s{S_NLEFT}, 0")
+    o("s_cbranch_scc1 2f")
+    mid = (list(cnt.lgkm), list(cnt.vm))
+    iteration(cnt, out, CB, CA, PB, PA, "B")
+    o(f"s_sub_u32 s{S_NLEFT}, s{S_NLEFT}, 1")
+    o(f"s_cmp_lg_u32 s{S_NLEFT}, 0")
+    o("s_cbranch_scc1 1b")
+    return mid
 
 
 def generate():
     out = []
     cnt = Counters(out)
     o = out.append
-    if DEBUG:
-        o(f"s_mov_b32 s{S_DBG}, %[dbg_lo]")
-        o(f"s_mov_b32 s{S_DBG + 1}, %[dbg_hi]")
-        o(f"s_add_u32 s{S_DBG + 2}, %[dbg_lo], 4096")
-        o(f"s_addc_u32 s{S_DBG + 3}, %[dbg_hi], 0")
-    o("; ===== prologue =====")
     o(f"s_mov_b32 s{S_XB}, %[xb_lo]")
     o(f"s_mov_b32 s{S_XB + 1}, %[xb_hi]")
-    o(f"s_mov_b32 s{S_TB}, %[tp_lo]")
-    o(f"s_mov_b32 s{S_TB + 1}, %[tp_hi]")
-    o(f"s_mov_b32 s{SB['A']['p']}, %[pp_lo]")
-    o(f"s_mov_b32 s{SB['A']['p'] + 1}, %[pp_hi]")
-    o(f"s_mov_b32 s{S_BF}, %[bf_lo]")
-    o(f"s_mov_b32 s{S_BF + 1}, %[bf_hi]")
+    o(f"s_mov_b32 s{S_P['A']}, %[pp_lo]")
+    o(f"s_mov_b32 s{S_P['A'] + 1}, %[pp_hi]")
     o(f"s_mov_b32 s{S_PSTRIDE}, %[pstride]")
     o(f"s_mov_b32 s{S_NLEFT}, %[nhi]")
-    o(f"s_add_u32 s{S_NHI1}, %[nhi], -1")
-    o(f"s_mov_b32 s{S_K}, 0")
-    o(f"v_mov_b32 {vr(V_SC)}, %[scale]")
-    o(f"s_mov_b32 s{S_RD}, 0")
-    o(f"s_mov_b32 s{S_RDN}, {SLOT}")
-    o(f"s_mov_b32 s{S_WR}, {2 * SLOT}")
-    o("s_nop 4")
-    # phasor-table operand images -> AGPRs (16 x 16 bytes per lane, 1 KiB apart).  Four
-    # bases, all computed before the first load: a base is never rewritten under a load.
-    BF = [S_BF, 66, 68, 70]
+    o(f"s_lshl_b32 s{S_KMAX}, %[nhi], 2")
+    o(f"s_sub_u32 s{S_KMAX}, s{S_KMAX}, 1")          # last k-step index
+    o(f"s_mov_b32 s{S_BF[0]}, %[bf_lo]")
+    o(f"s_mov_b32 s{S_BF[0] + 1}, %[bf_hi]")
     for j in range(1, 4):
-        o(f"s_add_u32 s{BF[j]}, s{S_BF}, {4096 * j}")
-        o(f"s_addc_u32 s{BF[j] + 1}, s{S_BF + 1}, 0")
+        o(f"s_add_u32 s{S_BF[j]}, %[bf_lo], {4096 * j}")
+        o(f"s_addc_u32 s{S_BF[j] + 1}, %[bf_hi], 0")
+    # bases of block 0
+    o(f"s_mov_b32 s{S_B}, 0")
+    for q in range(4):
+        o(f"v_add_u32 {vr(V_TB[q])}, {32 * q}, %[tb]")
+        out.extend(advance_x(q, 0))
     o("s_nop 4")
     for f in range(16):
-        b = BF[f // 4]
+        b = S_BF[f // 4]
         o(f"global_load_dwordx4 {ar(4 * f)}, %[bo], s[{b}:{b + 1}] offset:{(f % 4) * 1024}")
-    # zero: C set B, accumulators, P_B
-    for base in (CB[0], CB[1]):
-        for i in range(16):
-            o(f"v_accvgpr_write_b32 a{base + i}, 0")
-    for base in (ACC[0], ACC[1]):
+    for base in (CB[0], CB[1], ACC[0], ACC[1]):
         for i in range(16):
             o(f"v_mov_b32 {vr(base + i)}, 0")
     o(f"v_mov_b32 {vr(PB[0])}, 0")
     o(f"v_mov_b32 {vr(PB[1])}, 0")
-    # blocks 0 and 1 into ring slots 0 and 1, loads of block 2
-    for blk in range(2):
-        out.extend(advance_load_pointers("AB"[blk]))
-        o("s_nop 4")
-        gload_ops(cnt, out, "AB"[blk])
-        cnt.need_vm("xb")
-        if blk == 0:
-            dbg_store(out, 6, XB)
-            dbg_store(out, 7, HV)
-        out.extend(produce_ops())
-        if blk == 0:
-            dbg_store(out, 0, HI4)
-            dbg_store(out, 5, LO4)
-        o(f"v_add_u32 {vr(ADDR['B'][blk])}, {blk * SLOT}, %[wr16]")
-        o(f"ds_write_b128 {vr(ADDR['B'][blk])}, {vr(HI4, 4)}")
-        o(f"ds_write_b128 {vr(ADDR['B'][blk])}, {vr(LO4, 4)} offset:1024")
-        o("s_waitcnt lgkmcnt(0)")
-    out.extend(advance_load_pointers("B"))   # block 2, loaded here like an iteration "B" would
+    # x of k-steps 0..3, taps of k-steps 0 and 1; k-step 0 converted; then x of k-step 4,
+    # taps of k-step 2, and the bases the first trip expects already moved on
+    for q in range(4):
+        load_x(cnt, out, q, q)
+    load_h(cnt, out, 0, 0)
+    load_h(cnt, out, 1, 1)
+    o("s_waitcnt vmcnt(0)")
+    o("s_waitcnt lgkmcnt(0)")
+    cnt.vm, cnt.lgkm = [], []
+    out.extend(convert_ops(0, 0, 0))
+    out.extend(advance_x(0, 1))
+    out.extend(advance_x(1, 1))
+    out.extend(advance_x(2, 1))
+    out.extend(advance_h(0))
     o("s_nop 4")
-    o("s_waitcnt vmcnt(0)")          # phasor images landed (and nothing else outstanding)
-    cnt.vm = []
-    gload_ops(cnt, out, "B")
-    out.extend(advance_load_pointers("A"))   # block 3: iteration 0 ("A") loads it
-    V_RD, V_RDN, V_WR = ADDR["A"]
-    o(f"v_add_u32 {vr(V_RD)}, s{S_RD}, %[lane16]")
-    o(f"v_add_u32 {vr(V_RDN)}, s{S_RDN}, %[lane16]")
-    o(f"v_add_u32 {vr(V_WR)}, s{S_WR}, %[wr16]")
-    o("s_waitcnt lgkmcnt(0)")
-    o("s_barrier")
-    o(f"ds_read_b128 {vr(F0, 4)}, {vr(V_RD)}")
-    o(f"ds_read_b128 {vr(F0 + 4, 4)}, {vr(V_RD)} offset:1024")
-    o("s_waitcnt lgkmcnt(0)")
-    dbg_store(out, 1, F0)
-    cnt.lgkm = []
-    # steady state entry: vm = [hv, xa, xb]; the loop expects [p_prev, hv, xa, xb]
-    cnt.vm = ["prB", "pB", "hv", "xa", "xb"]
-    o("; ===== main loop, two blocks per trip =====")
-    o("1:")
-    iteration(cnt, out, CA, CB, PA, PB, "A")
-    o(f"s_sub_u32 s{S_NLEFT}, s{S_NLEFT}, 1")
-    o(f"s_cmp_eq_u32 s{S_NLEFT}, 0")
-    o("s_cbranch_scc1 2f")
-    state_a = (list(cnt.lgkm), list(cnt.vm))
-    iteration(cnt, out, CB, CA, PB, PA, "B")
-    o(f"s_sub_u32 s{S_NLEFT}, s{S_NLEFT}, 1")
-    o(f"s_cmp_lg_u32 s{S_NLEFT}, 0")
-    o("s_cbranch_scc1 1b")
-    if not os.environ.get("GEN_VM0"):
-        assert cnt.lgkm == [] and cnt.vm == ["prB", "pB", "hv", "xa", "xb"], (cnt.lgkm, cnt.vm)
-        assert state_a == ([], ["prA", "pA", "hv", "xa", "xb"]), state_a
-    # exits: P*C of the last block
-    o("; last block was in set B")
+    load_x(cnt, out, 0, 0)
+    load_h(cnt, out, 2, 0)
+    # the loop's first conversions expect k-steps 1..3 (x) and 1 (taps) pending in this order
+    cnt.vm = ["xa1", "xb1", "xa2", "xb2", "xa3", "xb3"] + cnt.vm
+    cnt.lgkm = ["h1"] + cnt.lgkm
+    entry = (list(cnt.lgkm), list(cnt.vm))
+    # steady-state counter state: simulate one trip, then emit from that state
+    sim = Counters([])
+    sim.lgkm, sim.vm = list(cnt.lgkm), list(cnt.vm)
+    body(sim, [])
+    steady = (list(sim.lgkm), list(sim.vm))
+    cnt.lgkm, cnt.vm = list(steady[0]), list(steady[1])
+    body(cnt, out)
+    assert (cnt.lgkm, cnt.vm) == steady, ((cnt.lgkm, cnt.vm), steady)
+    # the waits were computed for the steady state; at first entry the same loads are
+    # pending in the same order, minus the P loads of a previous block
+    if not ABLATE:
+        assert [t for t in steady[1] if not t.startswith("p")] == entry[1], (steady, entry)
+        assert steady[0] == entry[0], (steady, entry)
     o("s_waitcnt vmcnt(0)")
     o("s_nop 15")
     o("s_nop 15")
     out.extend(rotate_ops(CB, PB))
     o("s_branch 3f")
     o("2:")
-    o("; last block was in set A")
-    dbg_store(out, 2, F0 + 8)
-    dbg_store(out, 3, F0 + 16)
-    dbg_store(out, 4, F0 + 24)
     o("s_waitcnt vmcnt(0)")
     o("s_nop 15")
     o("s_nop 15")
     out.extend(rotate_ops(CA, PA))
     o("3:")
-    # hand the accumulators to the C++ epilogue through LDS (the ring is idle: every
-    # wave passed the barrier that ended the last iteration)
-    for q in range(8):
-        base = (ACC[0] if q < 4 else ACC[1]) + 4 * (q & 3)
-        o(f"ds_write_b128 %[accaddr], {vr(base, 4)} offset:{q * 1024}")
+    # the accumulators go to the C++ epilogue through LDS, over the taps table: every
+    # wave of the workgroup must be done reading it
+    o("s_waitcnt lgkmcnt(0)")
+    o("s_barrier")
+    for qd in range(8):
+        base = (ACC[0] if qd < 4 else ACC[1]) + 4 * (qd & 3)
+        o(f"ds_write_b128 %[accaddr], {vr(base, 4)} offset:{qd * 1024}")
     o("s_waitcnt lgkmcnt(0)")
     return out
 
@@ -464,17 +365,14 @@ def generate():
 def main():
     lines = generate()
     print("// GENERATED by tools/gen_ddc_mfma.py -- do not edit.")
-    print("// Main loop of ddc_mfma_asm_kernel: see the generator for the schedule and register map.")
+    print("// Main loop of ddc_mfma_asm_kernel: see the generator for the schedule, the register map and the rules.")
     print("#pragma once")
     print(f"#define GSDR_MFMA_ASM_VB {VB}")
-    print(f"#define GSDR_MFMA_ASM_RING_BYTES {3 * SLOT}")
     print("#define GSDR_MFMA_ASM_TEXT \\")
     for ln in lines:
-        if ln.startswith(";"):
-            continue
         print(f'    "{ln}\\n\\t" \\')
     print('    ""')
-    clob = [f'"v{i}"' for i in NVGPR_CLOBBER] + [f'"{"v" if BV else "a"}{(192 if BV else 0) + i}"' for i in range(NAGPR)] + \
+    clob = [f'"v{i}"' for i in NVGPR_CLOBBER] + [f'"a{i}"' for i in range(NAGPR)] + \
            [f'"s{i}"' for i in SGPR_CLOBBER] + ['"vcc"', '"scc"', '"memory"']
     print("#define GSDR_MFMA_ASM_CLOBBERS \\")
     for i in range(0, len(clob), 12):
