@@ -342,7 +342,9 @@ int setup_mfma(gsdr_demod *h, bool direct, const std::vector<long long> &tone) {
     // the assembly main loop (ddc_mfma_asm_kernel) exists for the default shape only;
     // GSDR_MFMA_ASM=0 keeps the compiler-scheduled kernel (A/B runs, tests)
     // (and for windows whose scaled taps fit its 40 KiB LDS table: 10240 - 128 taps)
-    if (env_int("GSDR_MFMA_ASM", 1) != 0 && h->mf_TT == 1 && h->mf_PK == 32 && h->mf_W == 4 &&
+    const int asm_kind = env_int("GSDR_MFMA_ASM", 2);   // 2: LDS operand ring (default), 1: ring-less loop, 0: C++
+    if (asm_kind == 2 && h->mf_TT == 1 && h->mf_PK == 32 && h->mf_W == 4) h->mf_sgb = 10;
+    if (asm_kind == 1 && h->mf_TT == 1 && h->mf_PK == 32 && h->mf_W == 4 &&
         ((M * F + 31) / 32) * 32 + 128 <= 10240)
         h->mf_sgb = 9;
     if (h->mf_W > h->mf_PK / 8) h->mf_W = h->mf_PK / 8;
@@ -407,7 +409,8 @@ int setup_mfma(gsdr_demod *h, bool direct, const std::vector<long long> &tone) {
         HIPCHK(h, hipMemset(h->d_dbg, 0xff, (size_t)env_int("GSDR_MFMA_DEBUG_BYTES", 0)));
     }
     h->mfma = true;
-    h->kernel_name = h->mf_sgb == 9 ? "ddc_mfma_asm_kernel" : gsdr::ddc_mfma_kernel_name();
+    h->kernel_name = h->mf_sgb == 9 ? "ddc_mfma_asm_kernel"
+                     : h->mf_sgb == 10 ? "ddc_mfma_ring_kernel" : gsdr::ddc_mfma_kernel_name();
     return 0;
 }
 
@@ -835,7 +838,7 @@ gsdr_demod *gsdr_demod_create(const gsdr_param_c *p) {
                 }
                 // (rows read whole 32-sample phasor blocks: the padding behind a window must stay
                 //  within the next block, or middle rows would read past the buffer)
-                if (!rc && env_int("GSDR_DDC_MFMA", 0) != 0 && h->L / M >= F - 1 && h->L >= 4 && F <= 33 &&
+                if (!rc && env_int("GSDR_DDC_MFMA", 1) != 0 && h->L / M >= F - 1 && h->L >= 4 && F <= 33 &&
                     (M * F + 31) / 32 * 32 - M * F <= M)
                     rc = setup_mfma(h, /*direct=*/true, tone);
                 if (!rc && !h->mfma) rc = autotune_chunks(h, (int)(h->L / M));
@@ -899,7 +902,7 @@ gsdr_demod *gsdr_demod_create(const gsdr_param_c *p) {
             // every carried sample of the raw window must come from the previous buffer
             // (absmax covers this buffer and the one before)
             // and the padding behind the last window must stay inside the raw buffer's spare half
-            if (!rc && env_int("GSDR_DDC_MFMA", 0) != 0 && (long long)h->nfft * (F + 1) <= h->L &&
+            if (!rc && env_int("GSDR_DDC_MFMA", 1) != 0 && (long long)h->nfft * (F + 1) <= h->L &&
                 (long long)h->nfft * h->batching >= 40)
                 rc = setup_mfma(h, /*direct=*/false, tone);
             if (!rc && !h->mfma) rc = autotune_chunks(h, (int)(h->L / h->nfft) + F - 1);

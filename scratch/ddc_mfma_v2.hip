@@ -28,7 +28,6 @@
 
 #include "ddc_device.h"
 #include "ddc_mfma_gen.h"
-#include "ddc_mfma_ring_gen.h"
 #ifndef GSDR_MFMA_LDS_UINT4
 #define GSDR_MFMA_LDS_UINT4 2048
 #endif
@@ -105,6 +104,17 @@ __device__ __forceinline__ void store_rows(const MfmaLaunch &a, int gt, int n0, 
             if (orow < sh.nout && n < sh.N) a.out[(size_t)orow * sh.N + n] = y;
         }
     }
+}
+
+// store_rows for the assembly kernel, compiled without packed-FP32 instructions:
+// while another wave of the SIMD runs the assembly loop (an MFMA every few vector
+// instructions), v_pk_*_f32 with a high-half operand select (op_sel:[1,..]) was
+// measured to return wrong values in a quarter-wave now and then
+// (scratch/mfma_probe.py, mfma_diag*.py); the compiler emits that form freely.
+__device__ __attribute__((noinline, target("no-packed-fp32-ops"))) void store_rows_nopk(
+    const MfmaLaunch &a, int gt, int n0, int hh, float invS, const float16v (&accr)[1],
+    const float16v (&acci)[1]) {
+    store_rows<1>(a, gt, n0, hh, invS, accr, acci);
 }
 
 // Workgroup barrier that no LDS access may be scheduled across (asm + memory
@@ -272,120 +282,14 @@ __global__ __launch_bounds__(64 * W, TT == 1 ? 2 : 1) void ddc_mfma_kernel(const
     store_rows<TT>(a, gt, n0, hh, invS, accr, acci);
 }
 
-// The same arithmetic with the main loop in assembly (tools/gen_ddc_mfma.py): one
-// tone tile per wave, four independent waves per workgroup (no LDS ring, no barrier
-// in the loop: every wave converts its own A operand; the workgroup shares only the
-// table of scaled taps in LDS and, through the L1, the input).  Everything around
-// the loop -- work split, scale, addresses, the stores -- is C++.
-constexpr int kAsmTaps = 10240;   // LDS table of the scaled taps, 40 KiB
-
-// (no packed FP32 in the whole kernel: rule R3 of the generator applies to the
-// compiler-generated code around the loop as well)
-__global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops"))) void ddc_mfma_asm_kernel(
-    const MfmaLaunch a) {
-    constexpr int KS = 4, W = 4;
-    __shared__ float table[kAsmTaps];   // taps while the loop runs, then the accumulators (4 x 8 KiB)
-    const MfmaShape &sh = a.sh;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int r = lane & 31, hh = lane >> 5;
-    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-    const int gt = (q / sh.ntq) * 8 + xcd;
-    if (gt >= sh.ngt) return;
-    const int tg_raw = (q % sh.ntq) * W + wave;
-    const bool active = tg_raw < sh.ntg;      // idle waves run the loop too (they meet the end barrier)
-    const int tg = active ? tg_raw : sh.ntg - 1;
-
-    const unsigned mb0 = a.maxbits[sh.slot_cur], mb1 = a.maxbits[sh.slot_prev];
-    const unsigned mb = mb0 > mb1 ? mb0 : mb1;
-    int se = 140 - (int)((mb >> 23) & 0xffu);
-    se = se > 100 ? 100 : (se < -100 ? -100 : se);
-    const float S = __uint_as_float((unsigned)(127 + se) << 23);
-    const float invS = __uint_as_float((unsigned)(127 - se) << 23) * sh.unscale;
-
-    // scaled taps with zeros behind them: the loop's look-ahead reads up to three
-    // k-steps past the window
-    const int nhi = (sh.nk8 + KS - 1) / KS;
-    const int ntaps = nhi * 32, nfill = ntaps + 128;
-    {
-        // every thread takes 4 taps per pass (16-byte loads, all issued before the first store)
-        constexpr int kPass = 10;                           // 10 * 1024 >= kAsmTaps
-        float4v t4[kPass];
-#pragma unroll
-        for (int k = 0; k < kPass; ++k) {
-            const int i = (k * 256 + (int)threadIdx.x) * 4;
-            t4[k] = i < ntaps ? *reinterpret_cast<const float4v *>(a.taps + i) : float4v{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int k = 0; k < kPass; ++k) {
-            const int i = (k * 256 + (int)threadIdx.x) * 4;
-            if (i < nfill) *reinterpret_cast<float4v *>(table + i) = t4[k] * S;
-        }
-    }
-    __syncthreads();
-
-    // scalar bases + per-lane non-negative byte offsets (global_load ..., voffset, s[base])
-    const int o = gt * 32 + r;
-    const int oc = o < sh.nout ? o : sh.nout - 1;
-    const float2 *xbase;           // sample s of this tile's rows lives at xbase[s + xshift]
-    long long xshift;
-    if (gt == 0) {
-        xbase = a.head;
-        xshift = sh.carry_len;
-    } else if (gt == sh.ngt - 1) {
-        xbase = a.tail;
-        xshift = -sh.tail0;
-    } else {
-        xbase = a.x;
-        xshift = 0;
-    }
-    const unsigned xo = (unsigned)((((long long)(oc + sh.woff) * sh.M + xshift) + 4 * hh) * 8);
-    const int Np = sh.NT32 * 32;
-    const int n0 = tg * 32 + r;
-    const unsigned po = (unsigned)n0 * 8u;
-    const unsigned bo = (unsigned)tg * (KS * 4 * 1024u) + (unsigned)lane * 16u;
-    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char *)table;
-    const unsigned tb = lds_base + 16u * (unsigned)hh;
-    const unsigned accaddr = lds_base + (unsigned)wave * 8192u + (unsigned)lane * 16u;
-    const unsigned long long xb = (unsigned long long)xbase, ppb = (unsigned long long)a.ptab,
-                             bfb = (unsigned long long)a.bfrag;
-    asm volatile(GSDR_MFMA_ASM_TEXT
-                 :
-                 : [xo] "v"(xo), [tb] "v"(tb), [po] "v"(po), [bo] "v"(bo), [accaddr] "v"(accaddr),
-                   [xb_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)xb)),
-                   [xb_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(xb >> 32))),
-                   [pp_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)ppb)),
-                   [pp_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(ppb >> 32))),
-                   [bf_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)bfb)),
-                   [bf_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(bfb >> 32))),
-                   [pstride] "s"(__builtin_amdgcn_readfirstlane((int)((unsigned)Np * 8u))),
-                   [nhi] "s"(__builtin_amdgcn_readfirstlane(nhi))
-                 : GSDR_MFMA_ASM_CLOBBERS);
-    if (!active) return;
-    float16v accr[1], acci[1];
-    const float4v *acc = reinterpret_cast<const float4v *>(table) + wave * 512 + lane;
-#pragma unroll
-    for (int qd = 0; qd < 4; ++qd) {
-        const float4v vr = acc[qd * 64], vi = acc[(qd + 4) * 64];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            accr[0][qd * 4 + j] = vr[j];
-            acci[0][qd * 4 + j] = vi[j];
-        }
-    }
-    store_rows<1>(a, gt, n0, hh, invS, accr, acci);
-}
-
-// Variant with the converted A operand shared through an LDS ring
-// (tools/gen_ddc_mfma_ring.py): each wave converts one k-step of every block, all
-// four read every k-step back.  A quarter of the loads and conversions of the
-// kernel above, one s_barrier per block.
-__global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops"))) void ddc_mfma_ring_kernel(
-    const MfmaLaunch a) {
+// The same kernel with its main loop in assembly (tools/gen_ddc_mfma.py): one tone
+// tile per wave, four waves, phasor block 32.  Everything around the loop -- work
+// split, scale, addresses, the final rotation and the stores -- is the C++ above.
+__global__ __launch_bounds__(256, 2) void ddc_mfma_asm_kernel(const MfmaLaunch a) {
     constexpr int KS = 4, W = 4;
     // ring (3 slots of 8 KiB) while the loop runs, then the accumulators (4 waves x 8 KiB)
-    __shared__ uint4 lds[2048];
-    static_assert(sizeof(uint4) * 2048 >= GSDR_MFMA_RING_BYTES, "ring fits");
+    __shared__ uint4 lds[GSDR_MFMA_LDS_UINT4];
+    static_assert(sizeof(uint4) * GSDR_MFMA_LDS_UINT4 >= GSDR_MFMA_ASM_RING_BYTES, "ring fits");
     const MfmaShape &sh = a.sh;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -404,9 +308,10 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
     const float S = __uint_as_float((unsigned)(127 + se) << 23);
     const float invS = __uint_as_float((unsigned)(127 - se) << 23) * sh.unscale;
 
+    // scalar bases + per-lane non-negative byte offsets (global_load ..., voffset, s[base])
     const int o = gt * 32 + r;
     const int oc = o < sh.nout ? o : sh.nout - 1;
-    const float2 *xbase;
+    const float2 *xbase;           // sample s of this tile's rows lives at xbase[s + xshift]
     long long xshift;
     if (gt == 0) {
         xbase = a.head;
@@ -428,28 +333,32 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
     const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char *)lds;
     const unsigned lane16 = lds_base + (unsigned)lane * 16u;
     const unsigned wr16 = lane16 + (unsigned)wave * 2048u;
-    const unsigned accaddr = lds_base + (unsigned)wave * 8192u + (unsigned)lane * 16u;
+    const unsigned accaddr = lds_base + GSDR_MFMA_ACC_OFF + (unsigned)wave * 8192u + (unsigned)lane * 16u;
     const unsigned long long xb = (unsigned long long)xbase, tpb = (unsigned long long)a.taps,
                              ppb = (unsigned long long)a.ptab, bfb = (unsigned long long)a.bfrag;
     const int nhi = (sh.nk8 + KS - 1) / KS;
-    asm volatile(GSDR_MFMA_RING_TEXT
+#ifdef GSDR_MFMA_ASM_DEBUG
+    const unsigned long long dbgb = (unsigned long long)a.dbg;
+    const unsigned dbgo = (unsigned)((blockIdx.x * 4 + wave) * 8192 + lane * 16);
+#endif
+    asm volatile(GSDR_MFMA_ASM_TEXT
                  :
-                 : [xo] "v"(xo), [to] "v"(to), [po] "v"(po), [bo] "v"(bo), [lane16] "v"(lane16), [wr16] "v"(wr16),
-                   [accaddr] "v"(accaddr), [xb_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)xb)),
-                   [xb_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(xb >> 32))),
-                   [tp_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)tpb)),
-                   [tp_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(tpb >> 32))),
-                   [pp_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)ppb)),
-                   [pp_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(ppb >> 32))),
-                   [bf_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)bfb)),
-                   [bf_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(bfb >> 32))),
-                   [pstride] "s"(__builtin_amdgcn_readfirstlane((int)((unsigned)Np * 8u))),
-                   [nhi] "s"(__builtin_amdgcn_readfirstlane(nhi)),
-                   [scale] "v"(S)
-                 : GSDR_MFMA_RING_CLOBBERS);
+                 :
+#ifdef GSDR_MFMA_ASM_DEBUG
+                   [dbgo] "v"(dbgo), [dbg_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)dbgb)),
+                   [dbg_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(dbgb >> 32))),
+#endif
+                   [xo] "v"(xo), [to] "v"(to), [po] "v"(po), [bo] "v"(bo), [lane16] "v"(lane16),
+                   [wr16] "v"(wr16), [accaddr] "v"(accaddr), [xb_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)xb)),
+                   [xb_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(xb >> 32))), [tp_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)tpb)),
+                   [tp_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(tpb >> 32))), [pp_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)ppb)),
+                   [pp_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(ppb >> 32))), [bf_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)bfb)),
+                   [bf_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(bfb >> 32))), [pstride] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)Np * 8u)), [nhi] "s"(__builtin_amdgcn_readfirstlane(nhi)),
+                   [scale] "s"(__builtin_amdgcn_readfirstlane((int)__float_as_uint(S)))
+                 : GSDR_MFMA_ASM_CLOBBERS);
     if (!active) return;
     float16v accr[1], acci[1];
-    const float4v *acc = reinterpret_cast<const float4v *>(lds) + wave * 512 + lane;
+    const float4v *acc = reinterpret_cast<const float4v *>(lds) + GSDR_MFMA_ACC_OFF / 16 + wave * 512 + lane;
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
         const float4v vr = acc[qd * 64], vi = acc[(qd + 4) * 64];
@@ -459,7 +368,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
             acci[0][qd * 4 + j] = vi[j];
         }
     }
-    store_rows<1>(a, gt, n0, hh, invS, accr, acci);
+    store_rows_nopk(a, gt, n0, hh, invS, accr, acci);
 }
 
 // One pass over the new buffer x[0..n):
@@ -468,69 +377,21 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
 //   * head_next[i - (n - carry_len)] = x[i] for the last carry_len samples (next call's carry);
 //   * tail[i - tail0] = x[i] for i >= tail0 (the last row tile reads there; zeros follow).
 // All destinations may be null.
-__global__ __launch_bounds__(256) void absmax_kernel(const float2 *x, long long n, long long chunk,
-                                                     unsigned *slots, int cur, int next, float2 *head_cur,
-                                                     long long head_n, float2 *head_next, int carry_len,
-                                                     float2 *tail, long long tail0) {
-    // one contiguous chunk of samples per workgroup (chunk is even)
-    const long long c0 = (long long)blockIdx.x * chunk;
-    const long long c1 = c0 + chunk < n ? c0 + chunk : n;
+__global__ __launch_bounds__(256) void absmax_kernel(const float2 *x, long long n, unsigned *slots,
+                                                     int cur, int next, float2 *head_cur,
+                                                     long long head_n, float2 *head_next,
+                                                     int carry_len, float2 *tail, long long tail0) {
+    const long long tid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long stride = (long long)gridDim.x * 256;
     unsigned m = 0;
-    const bool copies = (head_cur && c0 < head_n) || (head_next && c1 > n - carry_len) || (tail && c1 > tail0);
-    if (!copies) {
-        // fast path: 16-byte loads (two samples), four in flight per thread
-        const float4u *x4 = reinterpret_cast<const float4u *>(x + c0);
-        const long long pairs = (c1 - c0) >> 1;
-        long long i = threadIdx.x;
-        for (; i + 768 < pairs; i += 1024) {
-            const float4u v0 = x4[i], v1 = x4[i + 256], v2 = x4[i + 512], v3 = x4[i + 768];
-            const float4u q[4] = {v0, v1, v2, v3};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const unsigned b0 = __float_as_uint(q[k].x) & 0x7fffffffu, b1 = __float_as_uint(q[k].y) & 0x7fffffffu;
-                const unsigned b2 = __float_as_uint(q[k].z) & 0x7fffffffu, b3 = __float_as_uint(q[k].w) & 0x7fffffffu;
-                const unsigned u = b0 > b1 ? b0 : b1, w = b2 > b3 ? b2 : b3;
-                const unsigned t = u > w ? u : w;
-                m = m > t ? m : t;
-            }
-        }
-        for (; i < pairs; i += 256) {
-            const float4u v = x4[i];
-            const unsigned b0 = __float_as_uint(v.x) & 0x7fffffffu, b1 = __float_as_uint(v.y) & 0x7fffffffu;
-            const unsigned b2 = __float_as_uint(v.z) & 0x7fffffffu, b3 = __float_as_uint(v.w) & 0x7fffffffu;
-            const unsigned u = b0 > b1 ? b0 : b1, w = b2 > b3 ? b2 : b3;
-            const unsigned t = u > w ? u : w;
-            m = m > t ? m : t;
-        }
-        if (((c1 - c0) & 1) && threadIdx.x == 0) {
-            const float2 v = x[c1 - 1];
-            const unsigned b0 = __float_as_uint(v.x) & 0x7fffffffu, b1 = __float_as_uint(v.y) & 0x7fffffffu;
-            const unsigned t = b0 > b1 ? b0 : b1;
-            m = m > t ? m : t;
-        }
-    } else {
-        // chunk with copies: eight samples per thread in flight (the stores may alias
-        // nothing here, but the compiler cannot know: load first, then store)
-        for (long long base = c0 + threadIdx.x; base < c1; base += 2048) {
-            float2 v[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const long long i = base + 256 * k;
-                v[k] = i < c1 ? x[i] : make_float2(0.f, 0.f);
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const long long i = base + 256 * k;
-                if (i < c1) {
-                    const unsigned b0 = __float_as_uint(v[k].x) & 0x7fffffffu, b1 = __float_as_uint(v[k].y) & 0x7fffffffu;
-                    const unsigned t = b0 > b1 ? b0 : b1;
-                    m = m > t ? m : t;
-                    if (head_cur && i < head_n) head_cur[carry_len + i] = v[k];
-                    if (head_next && i >= n - carry_len) head_next[i - (n - carry_len)] = v[k];
-                    if (tail && i >= tail0) tail[i - tail0] = v[k];
-                }
-            }
-        }
+    for (long long i = tid; i < n; i += stride) {
+        const float2 v = x[i];
+        const unsigned b0 = __float_as_uint(v.x) & 0x7fffffffu, b1 = __float_as_uint(v.y) & 0x7fffffffu;
+        const unsigned t = b0 > b1 ? b0 : b1;
+        m = m > t ? m : t;
+        if (head_cur && i < head_n) head_cur[carry_len + i] = v;
+        if (head_next && i >= n - carry_len) head_next[i - (n - carry_len)] = v;
+        if (tail && i >= tail0) tail[i - tail0] = v;
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -545,8 +406,8 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float2 *x, long long 
         const unsigned u = wmax[0] > wmax[1] ? wmax[0] : wmax[1], w = wmax[2] > wmax[3] ? wmax[2] : wmax[3];
         const unsigned t = u > w ? u : w;
         if (t) atomicMax(&slots[cur], t);
-        if (blockIdx.x == 0) slots[next] = 0u;
     }
+    if (tid == 0) slots[next] = 0u;
 }
 
 // ---------------------------------------------------------------------------
@@ -669,14 +530,9 @@ hipError_t launch_absmax(const float2 *x, long long n, unsigned *slots, int cur,
                          float2 *tail, long long tail0, hipStream_t st) {
     if (n < 1 || carry_len < 0 || carry_len > n || head_n < 0 || head_n > n || tail0 < 0 || tail0 > n)
         return hipErrorInvalidValue;
-    // ~2 K samples per workgroup, at most 1024 workgroups, even chunks
-    long long blocks = (n + 2047) / 2048;
+    long long blocks = (n + 255) / 256;
     if (blocks > 1024) blocks = 1024;
-    if (blocks < 1) blocks = 1;
-    long long chunk = (n + blocks - 1) / blocks;
-    chunk += chunk & 1;
-    blocks = (n + chunk - 1) / chunk;
-    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n, chunk, slots, cur, next,
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n, slots, cur, next,
                        head_cur, head_n, head_next, carry_len, tail, tail0);
     return hipGetLastError();
 }
@@ -699,17 +555,8 @@ hipError_t launch_ddc_mfma(int TT, int PK, int W, int sgb, const MfmaLaunch &a, 
     if (a.x != a.tail && sh.ngt > 2 && (long long)(32 * (sh.ngt - 1) - 1 + sh.woff) * sh.M + reach > sh.nx)
         return hipErrorInvalidValue;
     if (sh.ngt > 1 && (long long)(32 * (sh.ngt - 1) + sh.woff) * sh.M < sh.tail0) return hipErrorInvalidValue;
-    if (sgb == 10) {  // assembly main loop with the LDS operand ring
-        if (TT != 1 || PK != 32 || W != 4) return hipErrorInvalidValue;
-        const int gt8 = (sh.ngt + 7) / 8;
-        const long long grid = (long long)gt8 * 8 * sh.ntq;
-        if (grid < 1 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(ddc_mfma_ring_kernel, dim3((unsigned)grid), dim3(256), 0, st, a);
-        return hipGetLastError();
-    }
     if (sgb == 9) {   // assembly main loop: one tone tile per wave, four waves, block 32
-        if (TT != 1 || PK != 32 || W != 4 || ((sh.nk8 + 3) / 4) * 32 + 128 > kAsmTaps)
-            return hipErrorInvalidValue;
+        if (TT != 1 || PK != 32 || W != 4) return hipErrorInvalidValue;
         const int gt8 = (sh.ngt + 7) / 8;
         const long long grid = (long long)gt8 * 8 * sh.ntq;
         if (grid < 1 || grid > 0x7fffffffLL) return hipErrorInvalidValue;

@@ -125,17 +125,21 @@ DIRECT_CASES = [
 
 @pytest.mark.parametrize("case", DIRECT_CASES, ids=lambda c: "N%d_M%d_F%d_L%d" % (c[0], c[2], c[3], c[4]))
 @pytest.mark.parametrize("impl", ["flat", "flat12", "flat16", "flat20", "simple16", "simple32",
-                                  "mfma", "mfma_c", "mfma_t2", "mfma_w2", "mfma_pk16"])
+                                  "mfma", "mfma_solo", "mfma_c", "mfma_t2", "mfma_w2", "mfma_pk16"])
 def test_direct_parity(cuda_device, gsdr_lib, oracle_mod, monkeypatch, case, impl):
     """flat* = ddc_flat_kernel (packed FP32; sub-block length auto / forced),
     simple* = ddc_kernel (generic fallback, phasor table 16 / 32),
-    mfma = ddc_mfma_asm_kernel (split-fp16 matrix cores, main loop in assembly),
+    mfma = ddc_mfma_ring_kernel (split-fp16 matrix cores, assembly main loop, operand
+    shared through an LDS ring: the production kernel),
+    mfma_solo = ddc_mfma_asm_kernel (assembly main loop, every wave converts its own operand),
     mfma_c* = ddc_mfma_kernel (same algorithm, compiler-scheduled; tone tiles per wave 1/2,
     waves per workgroup 4/2, phasor block 32/16)."""
     N, rate, M, F, L, nbuf = case
     if impl.startswith("mfma"):
         monkeypatch.setenv("GSDR_DDC_MFMA", "1")
-        if impl == "mfma_c":
+        if impl == "mfma_solo":
+            monkeypatch.setenv("GSDR_MFMA_ASM", "1")
+        if impl in ("mfma_c", "mfma_t2", "mfma_w2", "mfma_pk16"):
             monkeypatch.setenv("GSDR_MFMA_ASM", "0")
         if "_t" in impl:
             monkeypatch.setenv("GSDR_MFMA_TT", impl[-1])
