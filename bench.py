@@ -38,6 +38,7 @@ RATE = 200_000_000
 L = 1_000_000
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: FP32 vector == FP32 matrix peak
+F16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense f16/bf16 MFMA
 
 WORKLOADS = {
     # BASELINE.json configs[1]
@@ -339,8 +340,19 @@ def main():
         roof_hbm = dict(bound="hbm", achieved=round(gbs, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(gbs / HBM_PEAK_GBS, 5), traffic=traffic,
                         kernel=r["kernel"], kernel_us=round(kt * 1e6, 2))
-        if wl["kind"] in ("direct", "pfb"):
-            # fused DDC: ~1800 flop/B, FP32-compute bound. The FP32
+        if wl["kind"] in ("direct", "pfb") and r["kernel"].startswith("ddc_mfma"):
+            # matrix-core DDC: every (tone, sample, tap phase) is one complex MAC done as
+            # three fp16 x fp16 -> fp32 products of a hi/lo split: 3 * 4 real MACs = 24 flop
+            # on the f16 MFMA pipe; peak = dense f16 MFMA.
+            mf = 24.0 * wl["pf_average"] * r["n_tones"]
+            mtfl = mf * L / kt / 1e12
+            roof = dict(bound="mfma", pipe="f16 MFMA, fp32 accumulate, 3-product hi/lo split of fp32 operands",
+                        achieved=round(mtfl, 1), peak=F16_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                        frac=round(mtfl / F16_MFMA_PEAK_TFLOPS, 4), traffic=traffic,
+                        fp32_equivalent_tflops=round(tfl, 1),
+                        kernel=r["kernel"], kernel_us=round(kt * 1e6, 2))
+        elif wl["kind"] in ("direct", "pfb"):
+            # packed-FP32 DDC (GSDR_DDC_MFMA=0): FP32-compute bound. The FP32
             # vector peak equals the FP32 (f32-input) MFMA peak on gfx950: 157.3 TF.
             roof = dict(bound="mfma", pipe="fp32 valu (no MFMA used; same 157.3 TF peak)",
                         achieved=round(tfl, 3), peak=FP32_PEAK_TFLOPS, unit="TFLOP/s",
@@ -373,7 +385,11 @@ def main():
                 extras[key] = dict(msamples_per_s=round(100 * L / e["elapsed"] / 1e6, 2),
                                    kernel=e["kernel"], kernel_us=round(ekt * 1e6, 2),
                                    hbm_gbs=round(eb * L / ekt / 1e9, 2),
-                                   fp32_tflops=round(ef * L / ekt / 1e12, 3))
+                                   fp32_equivalent_tflops=round(ef * L / ekt / 1e12, 3))
+                if e["kernel"].startswith("ddc_mfma"):
+                    emf = 24.0 * WORKLOADS[key]["pf_average"] * e["n_tones"] * L / ekt / 1e12
+                    extras[key]["f16_mfma_tflops"] = round(emf, 1)
+                    extras[key]["f16_mfma_frac"] = round(emf / F16_MFMA_PEAK_TFLOPS, 4)
             best, probes = max_realtime_tones(device, seed)
             extras["max_realtime_tones_200Msps"] = dict(value=best, decim=1000, pf_average=4,
                                                         buffers=200, probes=probes)

@@ -10,7 +10,7 @@ rc=$?
 tail -4 gpurun_out/mfma_tests.log
 [ $rc -ne 0 ] && exit $rc
 for w in c2 c3 pfb; do
-  for asm in 0 1 2; do
+  for asm in 0 2; do
     GSDR_DDC_MFMA=1 GSDR_MFMA_ASM=$asm timeout -k 10 300 python bench.py --workload $w --steps 30 --warmup 5 --no-extras --no-cpu > gpurun_out/ab.log 2>&1 || { tail -5 gpurun_out/ab.log; exit 1; }
     grep -h '^{' gpurun_out/ab.log | python -c "
 import sys, json

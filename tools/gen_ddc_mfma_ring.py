@@ -39,7 +39,7 @@ NAGPR = 64
 # private SGPRs
 # scalar bases of the global loads, one set per iteration parity (same reason as
 # the ring address registers: never rewrite what a queued memory instruction reads)
-SB = {"A": dict(x=36, t=38, p=40), "B": dict(x=60, t=62, p=64)}
+SB = {"A": dict(x=36, t=38, p=40), "B": dict(x=60, t=62, p=64), "C": dict(x=76, t=78, p=0)}   # C: prologue only
 S_NLEFT, S_K, S_NHI1 = 42, 43, 44
 S_RD, S_RDN, S_WR = 45, 46, 47
 S_SC = 48      # s[48:49] = (S, S)
@@ -48,7 +48,7 @@ S_XB = 52      # s[52:53] x base, block 0
 S_TB = 54      # s[54:55] taps base, block 0
 S_BF = 56      # s[56:57] phasor-table images
 S_PSTRIDE = 58
-SGPR_CLOBBER = list(range(36, 76))
+SGPR_CLOBBER = list(range(36, 80))
 
 
 def vr(base, n=1):
@@ -122,13 +122,14 @@ def rotate_ops(cset, p):
     return ops
 
 
-def produce_ops():
+def produce_ops(xa=None, xb=None, hv=None):
     """x (4 complex samples in XA, XB) * taps (HV) * S -> fp16 hi (HI4) and lo (LO4):
     28 plain VALU instructions (no packed FP32, see tools/gen_ddc_mfma.py)."""
+    xa, xb, hv = (XA if xa is None else xa), (XB if xb is None else xb), (HV if hv is None else hv)
     ops = []
     for j in range(4):
-        ops.append(f"v_mul_f32 {vr(HS + j)}, {vr(HV + j)}, {vr(V_SC)}")
-    xs = [XA, XA + 2, XB, XB + 2]
+        ops.append(f"v_mul_f32 {vr(HS + j)}, {vr(hv + j)}, {vr(V_SC)}")
+    xs = [xa, xa + 2, xb, xb + 2]
     for j in range(4):
         ops.append(f"v_mul_f32 {vr(xs[j])}, {vr(xs[j])}, {vr(HS + j)}")
         ops.append(f"v_mul_f32 {vr(xs[j] + 1)}, {vr(xs[j] + 1)}, {vr(HS + j)}")
@@ -142,13 +143,14 @@ def produce_ops():
     return ops
 
 
-def gload_ops(cnt, out, par):
+def gload_ops(cnt, out, par, xa=None, xb=None, hv=None):
     S_X, S_T = SB[par]["x"], SB[par]["t"]
-    out.append(f"global_load_dwordx4 {vr(HV, 4)}, %[to], s[{S_T}:{S_T + 1}]")
+    xa, xb, hv = (XA if xa is None else xa), (XB if xb is None else xb), (HV if hv is None else hv)
+    out.append(f"global_load_dwordx4 {vr(hv, 4)}, %[to], s[{S_T}:{S_T + 1}]")
     cnt.issue_vm("hv")
-    out.append(f"global_load_dwordx4 {vr(XA, 4)}, %[xo], s[{S_X}:{S_X + 1}]")
+    out.append(f"global_load_dwordx4 {vr(xa, 4)}, %[xo], s[{S_X}:{S_X + 1}]")
     cnt.issue_vm("xa")
-    out.append(f"global_load_dwordx4 {vr(XB, 4)}, %[xo], s[{S_X}:{S_X + 1}] offset:16")
+    out.append(f"global_load_dwordx4 {vr(xb, 4)}, %[xo], s[{S_X}:{S_X + 1}] offset:16")
     cnt.issue_vm("xb")
 
 
@@ -332,28 +334,30 @@ def generate():
             o(f"v_mov_b32 {vr(base + i)}, 0")
     o(f"v_mov_b32 {vr(PB[0])}, 0")
     o(f"v_mov_b32 {vr(PB[1])}, 0")
-    # blocks 0 and 1 into ring slots 0 and 1, loads of block 2
-    for blk in range(2):
-        out.extend(advance_load_pointers("AB"[blk]))
-        o("s_nop 4")
-        gload_ops(cnt, out, "AB"[blk])
-        cnt.need_vm("xb")
-        if blk == 0:
-            dbg_store(out, 6, XB)
-            dbg_store(out, 7, HV)
-        out.extend(produce_ops())
-        if blk == 0:
-            dbg_store(out, 0, HI4)
-            dbg_store(out, 5, LO4)
+    # blocks 0, 1 and 2 are loaded at once (one round trip): block 0 into the input
+    # registers, 1 and 2 into the still idle operand buffers; 0 and 1 are converted
+    # into ring slots 0 and 1, block 2 is moved to the input registers for trip 0
+    T1 = (F0, F0 + 4, F0 + 8)          # xa, xb, hv of block 1
+    T2 = (F0 + 12, F0 + 16, F0 + 20)   # of block 2
+    out.extend(advance_load_pointers("A"))
+    out.extend(advance_load_pointers("B"))
+    out.extend(advance_load_pointers("C"))
+    o("s_nop 4")
+    gload_ops(cnt, out, "A")
+    gload_ops(cnt, out, "B", *T1)
+    gload_ops(cnt, out, "C", *T2)
+    o("s_waitcnt vmcnt(0)")          # the phasor images as well
+    cnt.vm = []
+    for blk, src in ((0, (None, None, None)), (1, T1)):
+        out.extend(produce_ops(*src))
         o(f"v_add_u32 {vr(ADDR['B'][blk])}, {blk * SLOT}, %[wr16]")
         o(f"ds_write_b128 {vr(ADDR['B'][blk])}, {vr(HI4, 4)}")
         o(f"ds_write_b128 {vr(ADDR['B'][blk])}, {vr(LO4, 4)} offset:1024")
         o("s_waitcnt lgkmcnt(0)")
-    out.extend(advance_load_pointers("B"))   # block 2, loaded here like an iteration "B" would
-    o("s_nop 4")
-    o("s_waitcnt vmcnt(0)")          # phasor images landed (and nothing else outstanding)
-    cnt.vm = []
-    gload_ops(cnt, out, "B")
+    for i in range(4):
+        o(f"v_mov_b32 {vr(XA + i)}, {vr(T2[0] + i)}")
+        o(f"v_mov_b32 {vr(XB + i)}, {vr(T2[1] + i)}")
+        o(f"v_mov_b32 {vr(HV + i)}, {vr(T2[2] + i)}")
     out.extend(advance_load_pointers("A"))   # block 3: iteration 0 ("A") loads it
     V_RD, V_RDN, V_WR = ADDR["A"]
     o(f"v_add_u32 {vr(V_RD)}, s{S_RD}, %[lane16]")
