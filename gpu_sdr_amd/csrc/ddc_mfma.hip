@@ -19,9 +19,17 @@
 // overflows and the lo halves stay normal; it comes from absmax_kernel's pass
 // over the buffer (max over this and the previous buffer, whose tail is the carry).
 //
-// Work split: one wave = 32 output rows x TT tiles of 32 tones; the four waves
-// of a workgroup take four tone groups of the same rows (they read the same x
-// through the CU's L1), and workgroups of the same rows sit on one XCD.
+// Work split: one wave = 32 output rows x 32 tones (x TT tiles in the C++ kernel); the
+// four waves of a workgroup take four tone groups of the same rows, and workgroups of
+// the same rows sit on one XCD.
+//
+// Three kernels, one algorithm (all parity-tested, tests/test_gpu_parity.py):
+//   ddc_mfma_ring_kernel  production: assembly main loop (tools/gen_ddc_mfma_ring.py),
+//                         converted A operand shared by the four waves through an LDS ring
+//   ddc_mfma_asm_kernel   assembly main loop (tools/gen_ddc_mfma.py), every wave converts
+//                         its own operand: no ring, no barrier in the loop (GSDR_MFMA_ASM=1)
+//   ddc_mfma_kernel       C++, compiler-scheduled, phases pinned with sched_barrier
+//                         (GSDR_MFMA_ASM=0; also windows too long for the assembly kernels)
 #include <cmath>
 #include <type_traits>
 #include <vector>
@@ -29,12 +37,6 @@
 #include "ddc_device.h"
 #include "ddc_mfma_gen.h"
 #include "ddc_mfma_ring_gen.h"
-#ifndef GSDR_MFMA_LDS_UINT4
-#define GSDR_MFMA_LDS_UINT4 2048
-#endif
-#ifndef GSDR_MFMA_ACC_OFF
-#define GSDR_MFMA_ACC_OFF 0u
-#endif
 
 namespace gsdr {
 

@@ -181,3 +181,22 @@ def test_no_cpu_fallback_in_product():
                 txt = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, f
                 assert "gsdr_oracle" not in txt and "liboracle" not in txt, f
+
+
+@pytest.mark.parametrize("gen,header", [("gen_ddc_mfma_ring.py", "ddc_mfma_ring_gen.h"),
+                                        ("gen_ddc_mfma.py", "ddc_mfma_gen.h"),
+                                        ("gen_ddc_steps.py", "ddc_steps_gen.h")])
+def test_generated_headers_are_current(gen, header):
+    """The committed assembly headers are exactly what their generators produce
+    (the two MFMA generators print, gen_ddc_steps.py rewrites its file)."""
+    import subprocess
+    import sys
+    path = os.path.join(ROOT, "gpu_sdr_amd", "csrc", header)
+    committed = open(path).read()
+    env = {k: v for k, v in os.environ.items() if not k.startswith("GEN_")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", gen)], capture_output=True, text=True,
+                         check=True, env=env).stdout
+    produced = open(path).read() if gen == "gen_ddc_steps.py" else out
+    if produced != committed:
+        open(path, "w").write(committed)      # leave the tree as it was
+    assert produced == committed
