@@ -90,7 +90,7 @@ struct MfmaLaunch {
     const float2 *ptab;        // [ceil(nk8/KS)][NT32*32]  w_n^(hi*PK)
     const float2 *dtab;        // [32][NT32*32]            w_n^(row*M)
     const unsigned *fmod;      // [NT32*32]
-    const unsigned *maxbits;   // [3] absmax slots
+    const unsigned *maxbits;   // [3][16] absmax slots (16 partial maxima each)
     float2 *out;
     void *dbg;                 // debug builds of the assembly loop dump registers here
     MfmaShape sh;

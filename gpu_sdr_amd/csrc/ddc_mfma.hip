@@ -80,6 +80,19 @@ __device__ __forceinline__ Frag make_frag(const float4v xa, const float4v xb, co
 
 }  // namespace
 
+// max |component| over this and the previous buffer: absmax_kernel keeps 16 partial
+// maxima per slot (float bits of non-negative numbers order like unsigned integers)
+__device__ __forceinline__ unsigned slot_max(const unsigned *slots, int cur, int prev) {
+    unsigned m = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const unsigned a = slots[cur * 16 + i], b = slots[prev * 16 + i];
+        const unsigned t = a > b ? a : b;
+        m = m > t ? m : t;
+    }
+    return m;
+}
+
 // rot[n,o] = w_n^(idx_base + o*M) / S applied to the accumulators, then the stores.
 template <int TT>
 __device__ __forceinline__ void store_rows(const MfmaLaunch &a, int gt, int n0, int hh, float invS,
@@ -172,8 +185,7 @@ __global__ __launch_bounds__(64 * W, TT == 1 ? 2 : 1) void ddc_mfma_kernel(const
                 }
 
     // ---- scale from the absmax pass ----
-    const unsigned mb0 = a.maxbits[sh.slot_cur], mb1 = a.maxbits[sh.slot_prev];
-    const unsigned mb = mb0 > mb1 ? mb0 : mb1;
+    const unsigned mb = slot_max(a.maxbits, sh.slot_cur, sh.slot_prev);
     int se = 140 - (int)((mb >> 23) & 0xffu);       // |x| < 2^(e-126), |h'| <= 1  =>  |b| < 2^14
     se = se > 100 ? 100 : (se < -100 ? -100 : se);
     const float S = __uint_as_float((unsigned)(127 + se) << 23);
@@ -298,8 +310,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
     const bool active = tg_raw < sh.ntg;      // idle waves run the loop too (they meet the end barrier)
     const int tg = active ? tg_raw : sh.ntg - 1;
 
-    const unsigned mb0 = a.maxbits[sh.slot_cur], mb1 = a.maxbits[sh.slot_prev];
-    const unsigned mb = mb0 > mb1 ? mb0 : mb1;
+    const unsigned mb = slot_max(a.maxbits, sh.slot_cur, sh.slot_prev);
     int se = 140 - (int)((mb >> 23) & 0xffu);
     se = se > 100 ? 100 : (se < -100 ? -100 : se);
     const float S = __uint_as_float((unsigned)(127 + se) << 23);
@@ -399,8 +410,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
     const bool active = tg_raw < sh.ntg;
     const int tg = active ? tg_raw : sh.ntg - 1;
 
-    const unsigned mb0 = a.maxbits[sh.slot_cur], mb1 = a.maxbits[sh.slot_prev];
-    const unsigned mb = mb0 > mb1 ? mb0 : mb1;
+    const unsigned mb = slot_max(a.maxbits, sh.slot_cur, sh.slot_prev);
     int se = 140 - (int)((mb >> 23) & 0xffu);
     se = se > 100 ? 100 : (se < -100 ? -100 : se);
     const float S = __uint_as_float((unsigned)(127 + se) << 23);
@@ -546,9 +556,10 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float2 *x, long long 
     if (threadIdx.x == 0) {
         const unsigned u = wmax[0] > wmax[1] ? wmax[0] : wmax[1], w = wmax[2] > wmax[3] ? wmax[2] : wmax[3];
         const unsigned t = u > w ? u : w;
-        if (t) atomicMax(&slots[cur], t);
-        if (blockIdx.x == 0) slots[next] = 0u;
+        // 16 addresses per slot: same-address atomics serialise (~10 ns each)
+        if (t) atomicMax(&slots[cur * 16 + (blockIdx.x & 15)], t);
     }
+    if (blockIdx.x == 0 && threadIdx.x < 16) slots[next * 16 + threadIdx.x] = 0u;
 }
 
 // ---------------------------------------------------------------------------
@@ -671,9 +682,9 @@ hipError_t launch_absmax(const float2 *x, long long n, unsigned *slots, int cur,
                          float2 *tail, long long tail0, hipStream_t st) {
     if (n < 1 || carry_len < 0 || carry_len > n || head_n < 0 || head_n > n || tail0 < 0 || tail0 > n)
         return hipErrorInvalidValue;
-    // ~2 K samples per workgroup, at most 1024 workgroups, even chunks
-    long long blocks = (n + 2047) / 2048;
-    if (blocks > 1024) blocks = 1024;
+    // ~4 K samples per workgroup, at most 512 workgroups, even chunks
+    long long blocks = (n + 4095) / 4096;
+    if (blocks > 512) blocks = 512;
     if (blocks < 1) blocks = 1;
     long long chunk = (n + blocks - 1) / blocks;
     chunk += chunk & 1;

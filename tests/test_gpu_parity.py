@@ -240,6 +240,55 @@ def test_pfb_and_chirp_fuzz_random_shapes(cuda_device, gsdr_lib, oracle_mod, eng
         dem.close()
 
 
+def test_mfma_dynamic_range_and_scale_carry(cuda_device, gsdr_lib, oracle_mod, monkeypatch):
+    """The matrix-core DDC scales every buffer into fp16 range from its own maximum (and
+    the previous buffer's, whose tail it still reads).  Same tolerance for inputs of
+    1e-6, 1 and 3e4, for a loud buffer followed by a quiet one and vice versa, and an
+    all-zero buffer gives exact zeros."""
+    monkeypatch.setenv("GSDR_DDC_MFMA", "1")
+    N, rate, M, F, L = 40, 10_000_000, 100, 4, 20_000
+    rng = np.random.default_rng(99)
+    freq = rng.integers(-rate // 2 + 1, rate // 2, size=N)
+    dem = make_direct(freq, rate, M, F, L)
+    assert dem.kernel_name.startswith("ddc_mfma")
+    ref = oracle_mod.Direct(freq, rate, M, F, L)
+    for c, scale in enumerate([1.0, 1e-6, 1e-6, 3e4, 1.0, 0.0, 1e-3, 0.0]):
+        x = (crandn(rng, L) * np.float32(scale)).astype(np.complex64)
+        y = run_device(dem, x, cuda_device).reshape(-1, N)
+        yr = ref.process(x)
+        assert np.isfinite(y.view(np.float32)).all(), (c, scale)
+        if scale == 0.0 and c == 7:
+            pass
+        den = np.linalg.norm(yr, axis=0)
+        if den.max() == 0:
+            assert np.abs(y).max() == 0
+            continue
+        # rows fed by the previous (louder) buffer's tail dominate the norm of a quiet
+        # buffer: compare where the reference itself is not ~0
+        err = np.linalg.norm(y - yr, axis=0) / np.where(den == 0, 1, den)
+        assert err.max() <= TOL, (c, scale, err.max())
+    dem.close()
+
+
+@pytest.mark.parametrize("F", [5, 6, 7, 8])
+def test_mfma_more_tap_phases(cuda_device, gsdr_lib, oracle_mod, monkeypatch, F):
+    """pf_average 5..8: the packed-FP32 production kernel stops at 4, the matrix-core DDC
+    takes any window that is made of whole blocks behind its last sample."""
+    monkeypatch.setenv("GSDR_DDC_MFMA", "1")
+    N, rate, M, L = 70, 1_000_000, 64, 64 * 300
+    rng = np.random.default_rng(F)
+    freq = rng.integers(-rate // 2 + 1, rate // 2, size=N)
+    dem = make_direct(freq, rate, M, F, L)
+    assert dem.kernel_name.startswith("ddc_mfma")
+    ref = oracle_mod.Direct(freq, rate, M, F, L)
+    for c in range(3):
+        x = crandn(rng, L)
+        y = run_device(dem, x, cuda_device).reshape(-1, N)
+        yr = ref.process(x)
+        assert rel_err_per_tone(y, yr).max() <= TOL
+    dem.close()
+
+
 def test_direct_streaming_equals_one_long_buffer(cuda_device, gsdr_lib, engine):
     """Concatenated per-buffer outputs == one call on the concatenated input."""
     rate, M, F, N = 1_000_000, 100, 4, 9
