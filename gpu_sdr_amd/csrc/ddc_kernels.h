@@ -92,7 +92,6 @@ struct MfmaLaunch {
     const unsigned *fmod;      // [NT32*32]
     const unsigned *maxbits;   // [3][16] absmax slots (16 partial maxima each)
     float2 *out;
-    void *dbg;                 // debug builds of the assembly loop dump registers here
     MfmaShape sh;
 };
 
@@ -109,8 +108,12 @@ void mfma_build_tables(const MfmaPlan &pl, const std::vector<unsigned> &fmod_in,
 hipError_t launch_absmax(const float2 *x, long long n, unsigned *slots, int cur, int next,
                          float2 *head_cur, long long head_n, float2 *head_next, int carry_len,
                          float2 *tail, long long tail0, hipStream_t st);
-hipError_t launch_ddc_mfma(int TT, int PK, int W, int sgb, const MfmaLaunch &a, hipStream_t st);
-const char *ddc_mfma_kernel_name();
+// AsmRing: assembly main loop, operand shared through an LDS ring (production);
+// AsmSolo: assembly main loop, every wave converts its own operand; Cxx: compiler-scheduled
+// (TT, PK, W apply to it only; the assembly kernels are TT = 1, PK = 32, W = 4).
+enum class MfmaKernel { AsmRing, AsmSolo, Cxx };
+hipError_t launch_ddc_mfma(MfmaKernel kind, int TT, int PK, int W, const MfmaLaunch &a, hipStream_t st);
+const char *ddc_mfma_kernel_name(MfmaKernel kind);
 
 // ---- chirp ---------------------------------------------------------------
 struct ChirpShape {

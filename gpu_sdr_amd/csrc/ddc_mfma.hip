@@ -31,6 +31,7 @@
 //   ddc_mfma_kernel       C++, compiler-scheduled, phases pinned with sched_barrier
 //                         (GSDR_MFMA_ASM=0; also windows too long for the assembly kernels)
 #include <cmath>
+#include <cstdlib>
 #include <type_traits>
 #include <vector>
 
@@ -150,7 +151,7 @@ __device__ __forceinline__ void wg_barrier() {
 //     only after the barrier that follows the VALU pass over all 32 results.
 //   * VALU reads of a VGPR-form MFMA result behind the compiler's own s_nop count
 //     returned stale upper registers (8..15); an explicit wait precedes them.
-template <int TT, int PK, int W, int SGB>
+template <int TT, int PK, int W>
 __global__ __launch_bounds__(64 * W, TT == 1 ? 2 : 1) void ddc_mfma_kernel(const MfmaLaunch a) {
     constexpr int KS = PK / 8;    // MFMA k-steps (8 complex samples each) per phasor block
     constexpr int SPW = KS / W;   // k-steps each wave produces per block
@@ -586,26 +587,19 @@ void host_phasor(unsigned long long ph, unsigned rate, double &re, double &im) {
 }
 
 template <int TT, int PK, int W>
-hipError_t launch_tpw(int sgb, const MfmaLaunch &a, hipStream_t st) {
+hipError_t launch_tpw(const MfmaLaunch &a, hipStream_t st) {
     const int gt8 = (a.sh.ngt + 7) / 8;
     const long long grid = (long long)gt8 * 8 * a.sh.ntq;
     if (grid < 1 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
-    const dim3 g((unsigned)grid), b(64 * W);
-    switch (sgb) {
-        case 0: hipLaunchKernelGGL((ddc_mfma_kernel<TT, PK, W, 0>), g, b, 0, st, a); break;
-        case 2: hipLaunchKernelGGL((ddc_mfma_kernel<TT, PK, W, 2>), g, b, 0, st, a); break;
-        case 3: hipLaunchKernelGGL((ddc_mfma_kernel<TT, PK, W, 3>), g, b, 0, st, a); break;
-        case 4: hipLaunchKernelGGL((ddc_mfma_kernel<TT, PK, W, 4>), g, b, 0, st, a); break;
-        default: return hipErrorInvalidValue;
-    }
+    hipLaunchKernelGGL((ddc_mfma_kernel<TT, PK, W>), dim3((unsigned)grid), dim3(64 * W), 0, st, a);
     return hipGetLastError();
 }
 
 template <int TT, int PK>
-hipError_t launch_tp(int W, int sgb, const MfmaLaunch &a, hipStream_t st) {
+hipError_t launch_tp(int W, const MfmaLaunch &a, hipStream_t st) {
     switch (W) {
-        case 2: return launch_tpw<TT, PK, 2>(sgb, a, st);
-        case 4: if constexpr (PK >= 32) return launch_tpw<TT, PK, 4>(sgb, a, st);
+        case 2: return launch_tpw<TT, PK, 2>(a, st);
+        case 4: if constexpr (PK >= 32) return launch_tpw<TT, PK, 4>(a, st);
         default: return hipErrorInvalidValue;
     }
 }
@@ -682,9 +676,14 @@ hipError_t launch_absmax(const float2 *x, long long n, unsigned *slots, int cur,
                          float2 *tail, long long tail0, hipStream_t st) {
     if (n < 1 || carry_len < 0 || carry_len > n || head_n < 0 || head_n > n || tail0 < 0 || tail0 > n)
         return hipErrorInvalidValue;
-    // ~4 K samples per workgroup, at most 512 workgroups, even chunks
-    long long blocks = (n + 4095) / 4096;
-    if (blocks > 512) blocks = 512;
+    // samples per workgroup (GSDR_ABSMAX_CHUNK, default 4096), at most 1024 workgroups, even chunks
+    static const long long want = [] {
+        const char *e = std::getenv("GSDR_ABSMAX_CHUNK");
+        const long long v = e ? std::atoll(e) : 4096;
+        return v >= 512 ? v : 4096;
+    }();
+    long long blocks = (n + want - 1) / want;
+    if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     long long chunk = (n + blocks - 1) / blocks;
     chunk += chunk & 1;
@@ -694,7 +693,7 @@ hipError_t launch_absmax(const float2 *x, long long n, unsigned *slots, int cur,
     return hipGetLastError();
 }
 
-hipError_t launch_ddc_mfma(int TT, int PK, int W, int sgb, const MfmaLaunch &a, hipStream_t st) {
+hipError_t launch_ddc_mfma(MfmaKernel kind, int TT, int PK, int W, const MfmaLaunch &a, hipStream_t st) {
     const MfmaShape &sh = a.sh;
     // shapes are checked on the host: a kernel reading past its tables faults the GPU
     if (sh.N < 1 || sh.nout < 1 || sh.M < 1 || sh.MF < 1 || sh.nk8 != (sh.MF + 7) / 8 ||
@@ -712,7 +711,7 @@ hipError_t launch_ddc_mfma(int TT, int PK, int W, int sgb, const MfmaLaunch &a, 
     if (a.x != a.tail && sh.ngt > 2 && (long long)(32 * (sh.ngt - 1) - 1 + sh.woff) * sh.M + reach > sh.nx)
         return hipErrorInvalidValue;
     if (sh.ngt > 1 && (long long)(32 * (sh.ngt - 1) + sh.woff) * sh.M < sh.tail0) return hipErrorInvalidValue;
-    if (sgb == 10) {  // assembly main loop with the LDS operand ring
+    if (kind == MfmaKernel::AsmRing) {
         if (TT != 1 || PK != 32 || W != 4) return hipErrorInvalidValue;
         const int gt8 = (sh.ngt + 7) / 8;
         const long long grid = (long long)gt8 * 8 * sh.ntq;
@@ -720,7 +719,7 @@ hipError_t launch_ddc_mfma(int TT, int PK, int W, int sgb, const MfmaLaunch &a, 
         hipLaunchKernelGGL(ddc_mfma_ring_kernel, dim3((unsigned)grid), dim3(256), 0, st, a);
         return hipGetLastError();
     }
-    if (sgb == 9) {   // assembly main loop: one tone tile per wave, four waves, block 32
+    if (kind == MfmaKernel::AsmSolo) {
         if (TT != 1 || PK != 32 || W != 4 || ((sh.nk8 + 3) / 4) * 32 + 128 > kAsmTaps)
             return hipErrorInvalidValue;
         const int gt8 = (sh.ngt + 7) / 8;
@@ -729,13 +728,15 @@ hipError_t launch_ddc_mfma(int TT, int PK, int W, int sgb, const MfmaLaunch &a, 
         hipLaunchKernelGGL(ddc_mfma_asm_kernel, dim3((unsigned)grid), dim3(256), 0, st, a);
         return hipGetLastError();
     }
-    if (TT == 2 && PK == 32) return launch_tp<2, 32>(W, sgb, a, st);
-    if (TT == 1 && PK == 32) return launch_tp<1, 32>(W, sgb, a, st);
-    if (TT == 2 && PK == 16) return launch_tp<2, 16>(W, sgb, a, st);
-    if (TT == 1 && PK == 16) return launch_tp<1, 16>(W, sgb, a, st);
+    if (TT == 2 && PK == 32) return launch_tp<2, 32>(W, a, st);
+    if (TT == 1 && PK == 32) return launch_tp<1, 32>(W, a, st);
+    if (TT == 2 && PK == 16) return launch_tp<2, 16>(W, a, st);
+    if (TT == 1 && PK == 16) return launch_tp<1, 16>(W, a, st);
     return hipErrorInvalidValue;
 }
 
-const char *ddc_mfma_kernel_name() { return "ddc_mfma_kernel"; }
+const char *ddc_mfma_kernel_name(MfmaKernel kind) {
+    return kind == MfmaKernel::AsmRing ? "ddc_mfma_ring_kernel" : kind == MfmaKernel::AsmSolo ? "ddc_mfma_asm_kernel" : "ddc_mfma_kernel";
+}
 
 }  // namespace gsdr

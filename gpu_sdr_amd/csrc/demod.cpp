@@ -91,7 +91,7 @@ struct gsdr_demod {
     // ---- DDC on the matrix cores (ddc_mfma.hip) ----
     bool mfma = false;
     int mf_TT = 1, mf_PK = 32, mf_W = 4;   // tone tiles per wave, phasor block, waves per workgroup
-    int mf_sgb = 4;                        // VALU instructions scheduled behind each MFMA (0: compiler's order)
+    gsdr::MfmaKernel mf_kind = gsdr::MfmaKernel::AsmRing;
     gsdr::MfmaShape mf{};              // fields that do not change between calls
     uint4 *d_bfrag = nullptr;
     float2 *d_ptab = nullptr, *d_dtab = nullptr;
@@ -99,7 +99,6 @@ struct gsdr_demod {
     unsigned *d_mfmod = nullptr, *d_maxbits = nullptr;
     float2 *d_head[2] = {nullptr, nullptr};     // [carry | first rows' samples | zeros], see absmax_kernel
     float2 *d_tail = nullptr;                   // [last rows' samples | zeros]
-    void *d_dbg = nullptr;                      // GSDR_MFMA_DEBUG_BYTES: register dump of debug builds
     int xparity = 0;
     unsigned long long call_no = 0;    // absmax slot rotation
     // ---- TONES ----
@@ -337,17 +336,14 @@ int setup_mfma(gsdr_demod *h, bool direct, const std::vector<long long> &tone) {
     h->mf_PK = env_int("GSDR_MFMA_PK", 32) == 16 ? 16 : 32;
     h->mf_W = env_int("GSDR_MFMA_W", 4);
     if (h->mf_W != 2 && h->mf_W != 4) h->mf_W = 4;
-    h->mf_sgb = env_int("GSDR_MFMA_SGB", 4);
-    if (h->mf_sgb != 0 && h->mf_sgb != 2 && h->mf_sgb != 3) h->mf_sgb = 4;
-    // the assembly main loop (ddc_mfma_asm_kernel) exists for the default shape only;
-    // GSDR_MFMA_ASM=0 keeps the compiler-scheduled kernel (A/B runs, tests)
-    // (and for windows whose scaled taps fit its 40 KiB LDS table: 10240 - 128 taps)
-    const int asm_kind = env_int("GSDR_MFMA_ASM", 2);   // 2: LDS operand ring (default), 1: ring-less loop, 0: C++
-    if (asm_kind == 2 && h->mf_TT == 1 && h->mf_PK == 32 && h->mf_W == 4) h->mf_sgb = 10;
-    if (asm_kind == 1 && h->mf_TT == 1 && h->mf_PK == 32 && h->mf_W == 4 &&
-        ((M * F + 31) / 32) * 32 + 128 <= 10240)
-        h->mf_sgb = 9;
-    if (h->mf_W > h->mf_PK / 8) h->mf_W = h->mf_PK / 8;
+    // the assembly main loops exist for the default shape only; GSDR_MFMA_ASM: 2 = LDS operand
+    // ring (default), 1 = ring-less loop (needs the scaled taps in its 40 KiB LDS table:
+    // 10240 - 128 taps), 0 = the compiler-scheduled kernel (A/B runs, tests)
+    const int asm_kind = env_int("GSDR_MFMA_ASM", 2);
+    const bool asm_shape = h->mf_TT == 1 && h->mf_PK == 32 && h->mf_W == 4;
+    h->mf_kind = gsdr::MfmaKernel::Cxx;
+    if (asm_kind == 2 && asm_shape) h->mf_kind = gsdr::MfmaKernel::AsmRing;
+    if (asm_kind == 1 && asm_shape && ((M * F + 31) / 32) * 32 + 128 <= 10240) h->mf_kind = gsdr::MfmaKernel::AsmSolo;
     gsdr::MfmaPlan pl{};
     pl.TT = h->mf_TT;
     pl.PK = h->mf_PK;
@@ -404,13 +400,8 @@ int setup_mfma(gsdr_demod *h, bool direct, const std::vector<long long> &tone) {
         HIPCHK(h, dev_alloc(&h->d_tail, tail_n));
         HIPCHK(h, hipMemset(h->d_tail, 0, tail_n * sizeof(float2)));
     }
-    if (env_int("GSDR_MFMA_DEBUG_BYTES", 0) > 0) {
-        HIPCHK(h, hipMalloc(&h->d_dbg, (size_t)env_int("GSDR_MFMA_DEBUG_BYTES", 0)));
-        HIPCHK(h, hipMemset(h->d_dbg, 0xff, (size_t)env_int("GSDR_MFMA_DEBUG_BYTES", 0)));
-    }
     h->mfma = true;
-    h->kernel_name = h->mf_sgb == 9 ? "ddc_mfma_asm_kernel"
-                     : h->mf_sgb == 10 ? "ddc_mfma_ring_kernel" : gsdr::ddc_mfma_kernel_name();
+    h->kernel_name = gsdr::ddc_mfma_kernel_name(h->mf_kind);
     return 0;
 }
 
@@ -558,10 +549,9 @@ int enqueue_mfma(gsdr_demod *h, const float2 *in, float2 *raw, long long raw_new
     a.fmod = h->d_mfmod;
     a.maxbits = h->d_maxbits;
     a.out = out;
-    a.dbg = h->d_dbg;
     hipEvent_t stop = nullptr;
     if (record_begin(h, st, &stop)) return -1;
-    HIPCHK(h, gsdr::launch_ddc_mfma(h->mf_TT, h->mf_PK, h->mf_W, h->mf_sgb, a, st));
+    HIPCHK(h, gsdr::launch_ddc_mfma(h->mf_kind, h->mf_TT, h->mf_PK, h->mf_W, a, st));
     if (stop) HIPCHK(h, hipEventRecord(stop, st));
     h->call_no++;
     return 0;
@@ -1087,17 +1077,11 @@ void gsdr_demod_close(gsdr_demod *h) {
                     h->d_wrem,    h->d_fmod,    h->d_tails,    h->d_carry[0], h->d_carry[1],
                     h->d_raw,     h->d_profile, h->d_ccarry[0], h->d_ccarry[1],
                     h->d_bfrag,   h->d_ptab,    h->d_dtab,     h->d_mtaps,    h->d_mfmod,
-                    h->d_maxbits, h->d_head[0], h->d_head[1], h->d_tail, h->d_dbg};
+                    h->d_maxbits, h->d_head[0], h->d_head[1], h->d_tail};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);  // ref: 03_implement.md:58-63
     delete h;
-}
-
-// debug builds only (not part of the ABI): copy the register dump of the assembly loop to the host
-extern "C" int gsdrx_debug_read(gsdr_demod *h, void *dst, long long bytes) {
-    if (!h || !h->d_dbg) return -1;
-    return hipMemcpy(dst, h->d_dbg, (size_t)bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
 
 int gsdr_demod_mode(const gsdr_demod *h) { return h ? h->mode : -1; }

@@ -1,5 +1,9 @@
 """Debug build of the assembly loop: dump producer/consumer registers (constant input,
-one-block window) and report which lanes/dwords deviate from the majority."""
+one-block window) and report which lanes/dwords deviate from the majority.
+
+Method record: the dump hooks (GEN_DEBUG in the generator, MfmaLaunch::dbg, gsdrx_debug_read)
+were removed from the product after the hunt; they are in git history (commit da7983e and
+its successors up to the "single load round trip" commit)."""
 import os, ctypes as C
 import numpy as np
 import torch

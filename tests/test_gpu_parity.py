@@ -145,7 +145,6 @@ def test_direct_parity(cuda_device, gsdr_lib, oracle_mod, monkeypatch, case, imp
             monkeypatch.setenv("GSDR_MFMA_TT", impl[-1])
         if "_w" in impl:
             monkeypatch.setenv("GSDR_MFMA_W", impl[-1])
-            monkeypatch.setenv("GSDR_MFMA_SGB", "0")
         if "_pk" in impl:
             monkeypatch.setenv("GSDR_MFMA_PK", impl[-2:])
     else:

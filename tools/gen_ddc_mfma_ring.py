@@ -55,12 +55,7 @@ def vr(base, n=1):
     return f"v{base}" if n == 1 else f"v[{base}:{base + n - 1}]"
 
 
-BV = int(os.environ.get("GEN_B_VGPR", "0"))   # experiment: phasor images in v[192:255] instead of AGPRs
-
-
 def ar(base, n=4):
-    if BV:
-        return f"v[{192 + base}:{192 + base + n - 1}]"
     return f"a[{base}:{base + n - 1}]"
 
 
@@ -278,28 +273,10 @@ def iteration(cnt, out, cur, prev, p_cur, p_prev, label):
     out.append("s_barrier")
 
 
-DEBUG = False
-S_DBG = 72   # s[72:73], s[74:75] = +4096
-
-
-def dbg_store(out, rec, reg):
-    """debug build: record `rec` (1 KiB per wave) <- v[reg:reg+3]"""
-    if not DEBUG:
-        return
-    b = S_DBG if rec < 4 else S_DBG + 2
-    out.append(f"global_store_dwordx4 %[dbgo], {vr(reg, 4)}, s[{b}:{b + 1}] offset:{(rec % 4) * 1024}")
-    out.append("s_waitcnt vmcnt(0)")
-
-
 def generate():
     out = []
     cnt = Counters(out)
     o = out.append
-    if DEBUG:
-        o(f"s_mov_b32 s{S_DBG}, %[dbg_lo]")
-        o(f"s_mov_b32 s{S_DBG + 1}, %[dbg_hi]")
-        o(f"s_add_u32 s{S_DBG + 2}, %[dbg_lo], 4096")
-        o(f"s_addc_u32 s{S_DBG + 3}, %[dbg_hi], 0")
     o("; ===== prologue =====")
     o(f"s_mov_b32 s{S_XB}, %[xb_lo]")
     o(f"s_mov_b32 s{S_XB + 1}, %[xb_hi]")
@@ -368,7 +345,6 @@ def generate():
     o(f"ds_read_b128 {vr(F0, 4)}, {vr(V_RD)}")
     o(f"ds_read_b128 {vr(F0 + 4, 4)}, {vr(V_RD)} offset:1024")
     o("s_waitcnt lgkmcnt(0)")
-    dbg_store(out, 1, F0)
     cnt.lgkm = []
     # steady state entry: vm = [hv, xa, xb]; the loop expects [p_prev, hv, xa, xb]
     cnt.vm = ["prB", "pB", "hv", "xa", "xb"]
@@ -395,9 +371,8 @@ def generate():
     o("s_branch 3f")
     o("2:")
     o("; last block was in set A")
-    dbg_store(out, 2, F0 + 8)
-    dbg_store(out, 3, F0 + 16)
-    dbg_store(out, 4, F0 + 24)
+
+
     o("s_waitcnt vmcnt(0)")
     o("s_nop 15")
     o("s_nop 15")
@@ -425,7 +400,7 @@ def main():
             continue
         print(f'    "{ln}\\n\\t" \\')
     print('    ""')
-    clob = [f'"v{i}"' for i in NVGPR_CLOBBER] + [f'"{"v" if BV else "a"}{(192 if BV else 0) + i}"' for i in range(NAGPR)] + \
+    clob = [f'"v{i}"' for i in NVGPR_CLOBBER] + [f'"a{i}"' for i in range(NAGPR)] + \
            [f'"s{i}"' for i in SGPR_CLOBBER] + ['"vcc"', '"scc"', '"memory"']
     print("#define GSDR_MFMA_RING_CLOBBERS \\")
     for i in range(0, len(clob), 12):
