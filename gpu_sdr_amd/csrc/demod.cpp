@@ -336,6 +336,7 @@ int setup_mfma(gsdr_demod *h, bool direct, const std::vector<long long> &tone) {
     h->mf_PK = env_int("GSDR_MFMA_PK", 32) == 16 ? 16 : 32;
     h->mf_W = env_int("GSDR_MFMA_W", 4);
     if (h->mf_W != 2 && h->mf_W != 4) h->mf_W = 4;
+    if (h->mf_W > h->mf_PK / 8) h->mf_W = h->mf_PK / 8;   // every wave converts whole k-steps
     // the assembly main loops exist for the default shape only; GSDR_MFMA_ASM: 2 = LDS operand
     // ring (default), 1 = ring-less loop (needs the scaled taps in its 40 KiB LDS table:
     // 10240 - 128 taps), 0 = the compiler-scheduled kernel (A/B runs, tests)
