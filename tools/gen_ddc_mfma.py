@@ -30,10 +30,11 @@ Rules this file keeps (each one cost a debugging session):
   R2  Address, data and scalar-base registers of a memory instruction stay unchanged
       for two k-steps after it was issued: with two workgroups on a CU they are read
       late (registers rewritten ~4 MFMAs later gave half of the lanes the new address).
-  R3  No v_pk_*_f32 with a high-half broadcast (op_sel:[1,..]): it returned wrong
-      values in lanes 48..63 now and then while another wave of the SIMD ran this
-      loop.  The loop has no packed FP32 at all (see above); the C++ epilogue of the
-      kernel is compiled without packed FP32 for this reason.
+  R3  No v_pk_*_f32 that broadcasts the HIGH half of a pair written by the packed
+      instruction in front of it (op_sel:[0,1] / [1,..]): it returned a stale value in
+      lanes 48..63 now and then while another wave of the SIMD ran this loop
+      (isolated reproducer: tools/ubench_pk_hazard.hip).  The loop has no packed FP32
+      at all (see above); the kernel around it is compiled without packed FP32.
   R4  s_waitcnt values come from a model of the counters (class Counters).
 
     python3 tools/gen_ddc_mfma.py > gpu_sdr_amd/csrc/ddc_mfma_gen.h
