@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
     const unsigned accaddr = lds_base + (unsigned)wave * 8192u + (unsigned)lane * 16u;
     const unsigned long long xb = (unsigned long long)xbase, tpb = (unsigned long long)a.taps,
                              ppb = (unsigned long long)a.ptab, bfb = (unsigned long long)a.bfrag;
-    const int nhi = (sh.nk8 + KS - 1) / KS;
+    const int nhi = (sh.timing_mode & 2) ? 1 : (sh.nk8 + KS - 1) / KS;
     asm volatile(GSDR_MFMA_RING_TEXT
                  :
                  : [xo] "v"(xo), [to] "v"(to), [po] "v"(po), [bo] "v"(bo), [lane16] "v"(lane16), [wr16] "v"(wr16),
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
                    [nhi] "s"(__builtin_amdgcn_readfirstlane(nhi)),
                    [scale] "v"(S)
                  : GSDR_MFMA_RING_CLOBBERS);
-    if (!active) return;
+    if (!active || (sh.timing_mode & 1)) return;
     float16v accr[1], acci[1];
     const float4v *acc = reinterpret_cast<const float4v *>(lds) + wave * 512 + lane;
 #pragma unroll

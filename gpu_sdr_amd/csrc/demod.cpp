@@ -388,6 +388,7 @@ int setup_mfma(gsdr_demod *h, bool direct, const std::vector<long long> &tone) {
     sh.inv_rate = 1.0 / (double)rate;
     sh.m_mod_rate = (unsigned)M % rate;
     sh.unscale = unscale;
+    sh.timing_mode = env_int("GSDR_MFMA_TIMING", 0);
     if (direct) {
         // row tile 0 and the last row tile read from copies with the carry in front
         // and zeros behind (sizes: ddc_mfma_kernel's reach, 8*nk8 samples per row)
