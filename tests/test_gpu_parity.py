@@ -288,6 +288,26 @@ def test_mfma_more_tap_phases(cuda_device, gsdr_lib, oracle_mod, monkeypatch, F)
     dem.close()
 
 
+def test_mfma_two_handles_interleaved(cuda_device, gsdr_lib, oracle_mod, monkeypatch):
+    """Two matrix-core demodulators fed alternately on one stream (the server's two RX front
+    ends): carry, scale slots and head/tail copies are per handle."""
+    monkeypatch.setenv("GSDR_DDC_MFMA", "1")
+    rng = np.random.default_rng(123)
+    cfgs = [(33, 10_000_000, 100, 4, 30_000), (70, 1_000_000, 40, 2, 16_000)]
+    dems, refs = [], []
+    for N, rate, M, F, L in cfgs:
+        freq = rng.integers(-rate // 2 + 1, rate // 2, size=N)
+        dems.append(make_direct(freq, rate, M, F, L))
+        refs.append(oracle_mod.Direct(freq, rate, M, F, L))
+    for c in range(4):
+        for k, (N, rate, M, F, L) in enumerate(cfgs):
+            x = (crandn(rng, L) * np.float32(10.0 ** (c - 2 * k))).astype(np.complex64)
+            y = run_device(dems[k], x, cuda_device).reshape(-1, N)
+            assert rel_err_per_tone(y, refs[k].process(x)).max() <= TOL, (c, k)
+    for d in dems:
+        d.close()
+
+
 def test_direct_streaming_equals_one_long_buffer(cuda_device, gsdr_lib, engine):
     """Concatenated per-buffer outputs == one call on the concatenated input."""
     rate, M, F, N = 1_000_000, 100, 4, 9
