@@ -515,6 +515,12 @@ def test_c3_2048_tones_decim1000_full_size(cuda_device, gsdr_lib, oracle_mod, en
     _full_size_direct(cuda_device, oracle_mod, N=2048, M=1000, nbuf=3, subset=12)
 
 
+def test_many_tones_16384_decim1000_full_size(cuda_device, gsdr_lib, oracle_mod):
+    """The regime of the max-real-time-tones figure: 16384 tones (512 tone tiles), oracle on
+    a subset, two buffers."""
+    _full_size_direct(cuda_device, oracle_mod, N=16384, M=1000, nbuf=2, subset=10)
+
+
 def test_pfb_full_size_1024_tones(cuda_device, gsdr_lib, oracle_mod, engine):
     """TONES at full buffer size: 1024 tones, the client's typical odd nfft (1230 does
     not divide 1e6: buffer_helper carry every call), oracle on a subset of tones."""
