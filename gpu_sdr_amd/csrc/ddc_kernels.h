@@ -93,6 +93,7 @@ struct MfmaLaunch {
     const unsigned *fmod;      // [NT32*32]
     const unsigned *maxbits;   // [3][16] absmax slots (16 partial maxima each)
     float2 *out;
+    float2 *carry_out;         // AsmRingDirect: receives x[nx - carry_len .. nx); `head` is the carry read
     MfmaShape sh;
 };
 
@@ -112,7 +113,7 @@ hipError_t launch_absmax(const float2 *x, long long n, unsigned *slots, int cur,
 // AsmRing: assembly main loop, operand shared through an LDS ring (production);
 // AsmSolo: assembly main loop, every wave converts its own operand; Cxx: compiler-scheduled
 // (TT, PK, W apply to it only; the assembly kernels are TT = 1, PK = 32, W = 4).
-enum class MfmaKernel { AsmRing, AsmSolo, Cxx };
+enum class MfmaKernel { AsmRing, AsmSolo, Cxx, AsmRingDirect };
 hipError_t launch_ddc_mfma(MfmaKernel kind, int TT, int PK, int W, const MfmaLaunch &a, hipStream_t st);
 const char *ddc_mfma_kernel_name(MfmaKernel kind);
 

@@ -38,6 +38,7 @@
 #include "ddc_device.h"
 #include "ddc_mfma_gen.h"
 #include "ddc_mfma_ring_gen.h"
+#include "ddc_mfma_ringd_gen.h"
 
 namespace gsdr {
 
@@ -94,32 +95,45 @@ __device__ __forceinline__ unsigned slot_max(const unsigned *slots, int cur, int
     return m;
 }
 
+// w_n^(idx_base + 32*gt*M): the phasor of tone n at the first row of row tile gt
+// (float pair; independent of the loop's results, so the assembly kernels take it
+// before their main loop, where it hides behind the first loads)
+__device__ __forceinline__ float2 tile_phasor(const MfmaLaunch &a, int gt, int n) {
+    const MfmaShape &sh = a.sh;
+    const unsigned long long s_tile = mod_rate(
+        (unsigned long long)sh.idx_base + (unsigned long long)(gt * 32) * sh.m_mod_rate, sh.rate, sh.rate_magic);
+    const unsigned long long ph = mod_rate((unsigned long long)a.fmod[n] * s_tile, sh.rate, sh.rate_magic);
+    double bre, bim;
+    exact_phasor(ph, sh.inv_rate, bre, bim);
+    return make_float2((float)bre, (float)bim);
+}
+
 // rot[n,o] = w_n^(idx_base + o*M) / S applied to the accumulators, then the stores.
+__device__ __forceinline__ void store_tile(const MfmaLaunch &a, int gt, int n, int hh, float invS, float2 base,
+                                           const float16v &accr, const float16v &acci) {
+    const MfmaShape &sh = a.sh;
+    const int Np = sh.NT32 * 32;
+    const float br = base.x * invS, bi = base.y * invS;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
+        const float2 d = a.dtab[(size_t)row * Np + n];
+        const float rr = br * d.x - bi * d.y, ri = br * d.y + bi * d.x;
+        float2 y;
+        y.x = accr[i] * rr - acci[i] * ri;
+        y.y = accr[i] * ri + acci[i] * rr;
+        const int orow = gt * 32 + row;
+        if (orow < sh.nout && n < sh.N) a.out[(size_t)orow * sh.N + n] = y;
+    }
+}
+
 template <int TT>
 __device__ __forceinline__ void store_rows(const MfmaLaunch &a, int gt, int n0, int hh, float invS,
                                            const float16v (&accr)[TT], const float16v (&acci)[TT]) {
-    const MfmaShape &sh = a.sh;
-    const int Np = sh.NT32 * 32;
-    const unsigned long long s_tile = mod_rate(
-        (unsigned long long)sh.idx_base + (unsigned long long)(gt * 32) * sh.m_mod_rate, sh.rate, sh.rate_magic);
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) {
         const int n = n0 + tt * 32;
-        const unsigned long long ph = mod_rate((unsigned long long)a.fmod[n] * s_tile, sh.rate, sh.rate_magic);
-        double bre, bim;
-        exact_phasor(ph, sh.inv_rate, bre, bim);
-        const float br = (float)bre * invS, bi = (float)bim * invS;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
-            const float2 d = a.dtab[(size_t)row * Np + n];
-            const float rr = br * d.x - bi * d.y, ri = br * d.y + bi * d.x;
-            float2 y;
-            y.x = accr[tt][i] * rr - acci[tt][i] * ri;
-            y.y = accr[tt][i] * ri + acci[tt][i] * rr;
-            const int orow = gt * 32 + row;
-            if (orow < sh.nout && n < sh.N) a.out[(size_t)orow * sh.N + n] = y;
-        }
+        store_tile(a, gt, n, hh, invS, tile_phasor(a, gt, n), accr[tt], acci[tt]);
     }
 }
 
@@ -445,6 +459,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
     const unsigned long long xb = (unsigned long long)xbase, tpb = (unsigned long long)a.taps,
                              ppb = (unsigned long long)a.ptab, bfb = (unsigned long long)a.bfrag;
     const int nhi = (sh.timing_mode & 2) ? 1 : (sh.nk8 + KS - 1) / KS;
+    const float2 base = tile_phasor(a, gt, n0);
     asm volatile(GSDR_MFMA_RING_TEXT
                  :
                  : [xo] "v"(xo), [to] "v"(to), [po] "v"(po), [bo] "v"(bo), [lane16] "v"(lane16), [wr16] "v"(wr16),
@@ -458,7 +473,9 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
                    [bf_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(bfb >> 32))),
                    [pstride] "s"(__builtin_amdgcn_readfirstlane((int)((unsigned)Np * 8u))),
                    [nhi] "s"(__builtin_amdgcn_readfirstlane(nhi)),
-                   [scale] "v"(S)
+                   [scale] "v"(S),
+                   // not read by the loop: operands only so that the phasor is finished before it
+                   [bx] "v"(base.x), [by] "v"(base.y)
                  : GSDR_MFMA_RING_CLOBBERS);
     if (!active || (sh.timing_mode & 1)) return;
     float16v accr[1], acci[1];
@@ -472,7 +489,132 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
             acci[0][qd * 4 + j] = vi[j];
         }
     }
-    store_rows<1>(a, gt, n0, hh, invS, accr, acci);
+    store_tile(a, gt, n0, hh, invS, base, accr[0], acci[0]);
+}
+
+// The ring kernel without its staging pass: ONE launch per buffer.  The loop reads the
+// caller's buffer and the carry directly (tools/gen_ddc_mfma_ring.py --direct: two
+// loads under complementary EXEC masks, clamped at the end of the buffer, where only
+// zero taps are met); the workgroup takes the maximum of exactly the samples its rows
+// read (its own power-of-two scale instead of one per buffer), and one workgroup copies
+// the last carry_len samples to the carry of the next call.  Needs M % 4 == 0: a group
+// of four samples then lies entirely in the carry or entirely in the buffer.
+__global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops"))) void ddc_mfma_ringd_kernel(
+    const MfmaLaunch a) {
+    constexpr int KS = 4, W = 4;
+    __shared__ uint4 lds[2048];
+    __shared__ unsigned wmax[W];
+    static_assert(sizeof(uint4) * 2048 >= GSDR_MFMA_RINGD_BYTES, "ring fits");
+    const MfmaShape &sh = a.sh;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = lane & 31, hh = lane >> 5;
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int gt = (q / sh.ntq) * 8 + xcd;
+    if (gt >= sh.ngt) return;
+    const int tg_raw = (q % sh.ntq) * W + wave;
+    const bool active = tg_raw < sh.ntg;
+    const int tg = active ? tg_raw : sh.ntg - 1;
+    const int nhi = (sh.timing_mode & 2) ? 1 : (sh.nk8 + KS - 1) / KS;
+    const int L = (int)sh.nx, cl = sh.carry_len;
+
+    if (gt == sh.ngt - 1 && q % sh.ntq == 0) {
+        const float2 *src = a.x + (L - cl);
+        for (int i = (int)threadIdx.x; i < cl; i += 256) a.carry_out[i] = src[i];
+    }
+
+    // max |component| over the samples of this row tile: [lo, hi) clipped to the buffer
+    const int o_last = gt * 32 + 31 < sh.nout ? gt * 32 + 31 : sh.nout - 1;
+    const int lo = (gt * 32 + sh.woff) * sh.M;
+    int hi = (o_last + sh.woff) * sh.M + nhi * 32;
+    hi = hi < L ? hi : L;
+    // (four groups in flight per thread: indices past the end are clamped, a sample seen
+    // twice does not change a maximum)
+    unsigned m = 0;
+    for (int sb = lo + 4 * (int)threadIdx.x; sb < hi; sb += 4096) {
+        float4u v[8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int s = sb + 1024 * u;
+            s = s < hi - 4 ? s : hi - 4;
+            const float2 *p = s < 0 ? a.head + (s + cl) : a.x + s;
+            v[2 * u] = reinterpret_cast<const float4u *>(p)[0];
+            v[2 * u + 1] = reinterpret_cast<const float4u *>(p)[1];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned b = __float_as_uint(v[u][j]) & 0x7fffffffu;
+                m = m > b ? m : b;
+            }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned t = (unsigned)__shfl_xor((int)m, d, 64);
+        m = m > t ? m : t;
+    }
+    if (lane == 0) wmax[wave] = m;
+    __syncthreads();
+    unsigned mb = wmax[0];
+#pragma unroll
+    for (int i = 1; i < W; ++i) mb = mb > wmax[i] ? mb : wmax[i];
+    mb = (unsigned)__builtin_amdgcn_readfirstlane((int)mb);
+    int se = 140 - (int)((mb >> 23) & 0xffu);
+    se = se > 100 ? 100 : (se < -100 ? -100 : se);
+    const float S = __uint_as_float((unsigned)(127 + se) << 23);
+    const float invS = __uint_as_float((unsigned)(127 - se) << 23) * sh.unscale;
+
+    const int o = gt * 32 + r;
+    const int oc = o < sh.nout ? o : sh.nout - 1;
+    // index of the first sample group this lane loads: k-step `wave` of block 0
+    const int s0 = (oc + sh.woff) * sh.M + 4 * hh + 8 * wave;
+    const unsigned to = (unsigned)((4 * hh + 8 * wave) * 4);
+    const int Np = sh.NT32 * 32;
+    const int n0 = tg * 32 + r;
+    const unsigned po = (unsigned)n0 * 8u;
+    const unsigned bo = (unsigned)tg * (KS * 4 * 1024u) + (unsigned)lane * 16u;
+    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char *)lds;
+    const unsigned lane16 = lds_base + (unsigned)lane * 16u;
+    const unsigned wr16 = lane16 + (unsigned)wave * 2048u;
+    const unsigned accaddr = lds_base + (unsigned)wave * 8192u + (unsigned)lane * 16u;
+    const unsigned long long xb = (unsigned long long)a.x, cb = (unsigned long long)a.head,
+                             tpb = (unsigned long long)a.taps, ppb = (unsigned long long)a.ptab,
+                             bfb = (unsigned long long)a.bfrag;
+    const float2 base = tile_phasor(a, gt, n0);
+    asm volatile(GSDR_MFMA_RINGD_TEXT
+                 :
+                 : [s0] "v"(s0), [to] "v"(to), [po] "v"(po), [bo] "v"(bo), [lane16] "v"(lane16), [wr16] "v"(wr16),
+                   [accaddr] "v"(accaddr), [xb_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)xb)),
+                   [xb_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(xb >> 32))),
+                   [cb_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)cb)),
+                   [cb_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(cb >> 32))),
+                   [smax] "s"(__builtin_amdgcn_readfirstlane(L - 4)),
+                   [cl8] "s"(__builtin_amdgcn_readfirstlane(cl * 8)),
+                   [tp_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)tpb)),
+                   [tp_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(tpb >> 32))),
+                   [pp_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)ppb)),
+                   [pp_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(ppb >> 32))),
+                   [bf_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)bfb)),
+                   [bf_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(bfb >> 32))),
+                   [pstride] "s"(__builtin_amdgcn_readfirstlane((int)((unsigned)Np * 8u))),
+                   [nhi] "s"(__builtin_amdgcn_readfirstlane(nhi)),
+                   [scale] "v"(S),
+                   [bx] "v"(base.x), [by] "v"(base.y)
+                 : GSDR_MFMA_RINGD_CLOBBERS);
+    if (!active || (sh.timing_mode & 1)) return;
+    float16v accr[1], acci[1];
+    const float4v *acc = reinterpret_cast<const float4v *>(lds) + wave * 512 + lane;
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+        const float4v vr = acc[qd * 64], vi = acc[(qd + 4) * 64];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            accr[0][qd * 4 + j] = vr[j];
+            acci[0][qd * 4 + j] = vi[j];
+        }
+    }
+    store_tile(a, gt, n0, hh, invS, base, accr[0], acci[0]);
 }
 
 // One pass over the new buffer x[0..n):
@@ -711,6 +853,18 @@ hipError_t launch_ddc_mfma(MfmaKernel kind, int TT, int PK, int W, const MfmaLau
     if (a.x != a.tail && sh.ngt > 2 && (long long)(32 * (sh.ngt - 1) - 1 + sh.woff) * sh.M + reach > sh.nx)
         return hipErrorInvalidValue;
     if (sh.ngt > 1 && (long long)(32 * (sh.ngt - 1) + sh.woff) * sh.M < sh.tail0) return hipErrorInvalidValue;
+    if (kind == MfmaKernel::AsmRingDirect) {
+        // one launch: buffer and carry are read in place, clamped at nx - 4
+        if (TT != 1 || PK != 32 || W != 4 || sh.M % 4 != 0 || sh.nx < 4 || sh.nx % 4 != 0 ||
+            sh.nx > 0x0fffffffLL || sh.carry_len != -sh.woff * sh.M || sh.carry_len > sh.nx ||
+            sh.nx != (long long)sh.nout * sh.M || !a.carry_out || a.carry_out == a.head)
+            return hipErrorInvalidValue;
+        const int gt8 = (sh.ngt + 7) / 8;
+        const long long grid = (long long)gt8 * 8 * sh.ntq;
+        if (grid < 1 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(ddc_mfma_ringd_kernel, dim3((unsigned)grid), dim3(256), 0, st, a);
+        return hipGetLastError();
+    }
     if (kind == MfmaKernel::AsmRing) {
         if (TT != 1 || PK != 32 || W != 4) return hipErrorInvalidValue;
         const int gt8 = (sh.ngt + 7) / 8;
@@ -736,7 +890,7 @@ hipError_t launch_ddc_mfma(MfmaKernel kind, int TT, int PK, int W, const MfmaLau
 }
 
 const char *ddc_mfma_kernel_name(MfmaKernel kind) {
-    return kind == MfmaKernel::AsmRing ? "ddc_mfma_ring_kernel" : kind == MfmaKernel::AsmSolo ? "ddc_mfma_asm_kernel" : "ddc_mfma_kernel";
+    return kind == MfmaKernel::AsmRingDirect ? "ddc_mfma_ringd_kernel" : kind == MfmaKernel::AsmRing ? "ddc_mfma_ring_kernel" : kind == MfmaKernel::AsmSolo ? "ddc_mfma_asm_kernel" : "ddc_mfma_kernel";
 }
 
 }  // namespace gsdr

@@ -345,6 +345,11 @@ int setup_mfma(gsdr_demod *h, bool direct, const std::vector<long long> &tone) {
     h->mf_kind = gsdr::MfmaKernel::Cxx;
     if (asm_kind == 2 && asm_shape) h->mf_kind = gsdr::MfmaKernel::AsmRing;
     if (asm_kind == 1 && asm_shape && ((M * F + 31) / 32) * 32 + 128 <= 10240) h->mf_kind = gsdr::MfmaKernel::AsmSolo;
+    // 3 = the ring kernel reading buffer and carry in place: one launch per buffer (DIRECT,
+    // M % 4 == 0; other shapes fall back to 2)
+    if (asm_kind == 3 && asm_shape)
+        h->mf_kind = direct && M % 4 == 0 && h->L < 0x10000000LL ? gsdr::MfmaKernel::AsmRingDirect
+                                                                  : gsdr::MfmaKernel::AsmRing;
     gsdr::MfmaPlan pl{};
     pl.TT = h->mf_TT;
     pl.PK = h->mf_PK;
@@ -530,6 +535,13 @@ int enqueue_mfma(gsdr_demod *h, const float2 *in, float2 *raw, long long raw_new
                                       nullptr, h->L, st));
         a.x = a.head = a.tail = raw;
         a.sh.tail0 = 0;
+    } else if (h->mf_kind == gsdr::MfmaKernel::AsmRingDirect) {
+        // single launch: d_head[] only hold the carry (their first carry_len samples)
+        a.x = a.tail = in;
+        a.head = h->d_head[h->xparity];
+        a.carry_out = h->d_head[h->xparity ^ 1];
+        a.sh.tail0 = 0;
+        h->xparity ^= 1;
     } else {
         const int cl = a.sh.carry_len;
         const long long t0 = a.sh.ngt > 1 ? (long long)(32 * (a.sh.ngt - 1) + a.sh.woff) * a.sh.M : h->L;

@@ -68,10 +68,21 @@ def make_chirp(rate, f0, f1, steps, t, decim, L):
     return g.RX_buffer_demodulator(p, device_index=0)
 
 
-@pytest.fixture(params=["flat", "mfma"])
+@pytest.fixture(params=["flat", "mfma", "mfma1"])
 def engine(request, monkeypatch):
-    """Runs a test once per DDC engine: packed-FP32 VALU kernel, matrix-core kernel."""
-    monkeypatch.setenv("GSDR_DDC_MFMA", "1" if request.param == "mfma" else "0")
+    """Runs a test once per DDC engine: packed-FP32 VALU kernel, matrix-core kernel behind
+    its staging pass, matrix-core kernel reading buffer and carry in place (one launch;
+    shapes it does not take -- M % 4 != 0, TONES -- fall back to the staged one)."""
+    monkeypatch.setenv("GSDR_DDC_MFMA", "0" if request.param == "flat" else "1")
+    monkeypatch.setenv("GSDR_MFMA_ASM", "3" if request.param == "mfma1" else "2")
+    return request.param
+
+
+@pytest.fixture(params=["staged", "direct"])
+def mfma_engine(request, monkeypatch):
+    """Matrix-core DDC behind its staging pass / reading buffer and carry in place."""
+    monkeypatch.setenv("GSDR_DDC_MFMA", "1")
+    monkeypatch.setenv("GSDR_MFMA_ASM", "3" if request.param == "direct" else "2")
     return request.param
 
 
@@ -125,18 +136,24 @@ DIRECT_CASES = [
 
 @pytest.mark.parametrize("case", DIRECT_CASES, ids=lambda c: "N%d_M%d_F%d_L%d" % (c[0], c[2], c[3], c[4]))
 @pytest.mark.parametrize("impl", ["flat", "flat12", "flat16", "flat20", "simple16", "simple32",
-                                  "mfma", "mfma_solo", "mfma_c", "mfma_t2", "mfma_w2", "mfma_pk16"])
+                                  "mfma", "mfma_direct", "mfma_solo", "mfma_c", "mfma_t2", "mfma_w2", "mfma_pk16"])
 def test_direct_parity(cuda_device, gsdr_lib, oracle_mod, monkeypatch, case, impl):
     """flat* = ddc_flat_kernel (packed FP32; sub-block length auto / forced),
     simple* = ddc_kernel (generic fallback, phasor table 16 / 32),
     mfma = ddc_mfma_ring_kernel (split-fp16 matrix cores, assembly main loop, operand
     shared through an LDS ring: the production kernel),
+    mfma_direct = ddc_mfma_ringd_kernel (the same loop reading buffer and carry in place: one
+    launch per buffer, one scale per workgroup; M % 4 == 0, other shapes run the staged kernel),
     mfma_solo = ddc_mfma_asm_kernel (assembly main loop, every wave converts its own operand),
     mfma_c* = ddc_mfma_kernel (same algorithm, compiler-scheduled; tone tiles per wave 1/2,
     waves per workgroup 4/2, phasor block 32/16)."""
     N, rate, M, F, L, nbuf = case
     if impl.startswith("mfma"):
         monkeypatch.setenv("GSDR_DDC_MFMA", "1")
+        if impl == "mfma":
+            monkeypatch.setenv("GSDR_MFMA_ASM", "2")
+        if impl == "mfma_direct":
+            monkeypatch.setenv("GSDR_MFMA_ASM", "3")
         if impl == "mfma_solo":
             monkeypatch.setenv("GSDR_MFMA_ASM", "1")
         if impl in ("mfma_c", "mfma_t2", "mfma_w2", "mfma_pk16"):
@@ -158,6 +175,8 @@ def test_direct_parity(cuda_device, gsdr_lib, oracle_mod, monkeypatch, case, imp
     dem = make_direct(freq, rate, M, F, L)
     ref = oracle_mod.Direct(freq, rate, M, F, L)
     np.testing.assert_array_equal(dem.window(), ref.taps())
+    if impl == "mfma_direct" and dem.kernel_name.startswith("ddc_mfma"):
+        assert dem.kernel_name == ("ddc_mfma_ringd_kernel" if M % 4 == 0 else "ddc_mfma_ring_kernel")
     for c in range(nbuf):
         x = crandn(rng, L)
         y = (run_host if c % 2 else run_device)(dem, x, *(() if c % 2 else (cuda_device,)))
@@ -239,12 +258,11 @@ def test_pfb_and_chirp_fuzz_random_shapes(cuda_device, gsdr_lib, oracle_mod, eng
         dem.close()
 
 
-def test_mfma_dynamic_range_and_scale_carry(cuda_device, gsdr_lib, oracle_mod, monkeypatch):
+def test_mfma_dynamic_range_and_scale_carry(cuda_device, gsdr_lib, oracle_mod, mfma_engine):
     """The matrix-core DDC scales every buffer into fp16 range from its own maximum (and
     the previous buffer's, whose tail it still reads).  Same tolerance for inputs of
     1e-6, 1 and 3e4, for a loud buffer followed by a quiet one and vice versa, and an
     all-zero buffer gives exact zeros."""
-    monkeypatch.setenv("GSDR_DDC_MFMA", "1")
     N, rate, M, F, L = 40, 10_000_000, 100, 4, 20_000
     rng = np.random.default_rng(99)
     freq = rng.integers(-rate // 2 + 1, rate // 2, size=N)
@@ -270,10 +288,9 @@ def test_mfma_dynamic_range_and_scale_carry(cuda_device, gsdr_lib, oracle_mod, m
 
 
 @pytest.mark.parametrize("F", [5, 6, 7, 8])
-def test_mfma_more_tap_phases(cuda_device, gsdr_lib, oracle_mod, monkeypatch, F):
+def test_mfma_more_tap_phases(cuda_device, gsdr_lib, oracle_mod, mfma_engine, F):
     """pf_average 5..8: the packed-FP32 production kernel stops at 4, the matrix-core DDC
     takes any window that is made of whole blocks behind its last sample."""
-    monkeypatch.setenv("GSDR_DDC_MFMA", "1")
     N, rate, M, L = 70, 1_000_000, 64, 64 * 300
     rng = np.random.default_rng(F)
     freq = rng.integers(-rate // 2 + 1, rate // 2, size=N)
@@ -288,10 +305,9 @@ def test_mfma_more_tap_phases(cuda_device, gsdr_lib, oracle_mod, monkeypatch, F)
     dem.close()
 
 
-def test_mfma_two_handles_interleaved(cuda_device, gsdr_lib, oracle_mod, monkeypatch):
+def test_mfma_two_handles_interleaved(cuda_device, gsdr_lib, oracle_mod, mfma_engine):
     """Two matrix-core demodulators fed alternately on one stream (the server's two RX front
     ends): carry, scale slots and head/tail copies are per handle."""
-    monkeypatch.setenv("GSDR_DDC_MFMA", "1")
     rng = np.random.default_rng(123)
     cfgs = [(33, 10_000_000, 100, 4, 30_000), (70, 1_000_000, 40, 2, 16_000)]
     dems, refs = [], []

@@ -184,6 +184,7 @@ def test_no_cpu_fallback_in_product():
 
 
 @pytest.mark.parametrize("gen,header", [("gen_ddc_mfma_ring.py", "ddc_mfma_ring_gen.h"),
+                                        ("gen_ddc_mfma_ring.py --direct", "ddc_mfma_ringd_gen.h"),
                                         ("gen_ddc_mfma.py", "ddc_mfma_gen.h"),
                                         ("gen_ddc_steps.py", "ddc_steps_gen.h")])
 def test_generated_headers_are_current(gen, header):
@@ -194,7 +195,8 @@ def test_generated_headers_are_current(gen, header):
     path = os.path.join(ROOT, "gpu_sdr_amd", "csrc", header)
     committed = open(path).read()
     env = {k: v for k, v in os.environ.items() if not k.startswith("GEN_")}
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", gen)], capture_output=True, text=True,
+    gen, *flags = gen.split()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", gen)] + flags, capture_output=True, text=True,
                          check=True, env=env).stdout
     produced = open(path).read() if gen == "gen_ddc_steps.py" else out
     if produced != committed:

@@ -11,10 +11,21 @@ per wave and block.  The rules R1..R4 of tools/gen_ddc_mfma.py apply; the ring
 address registers and the scalar load bases exist once per iteration parity (R2).
 
     python3 tools/gen_ddc_mfma_ring.py > gpu_sdr_amd/csrc/ddc_mfma_ring_gen.h
+    python3 tools/gen_ddc_mfma_ring.py --direct > gpu_sdr_amd/csrc/ddc_mfma_ringd_gen.h
+
+--direct: the loop reads the caller's buffer and the carry (the last (F-1)*M samples
+of the previous buffer) itself instead of the head / tail copies a staging kernel
+laid out: one kernel launch per buffer.  Every lane keeps the index s of the sample
+group it loads next; s < 0 is served from the carry, s > L-4 is clamped (those
+samples only ever meet zero taps).  The two sources are two loads under
+complementary EXEC masks; their offsets and the mask exist once per iteration
+parity (R2) and are rewritten only after the previous loads of that parity have
+been waited for.
 """
 import os
 import sys
 
+DIRECT = "--direct" in sys.argv
 KS = 4                     # k-steps per block (PK = 32)
 SLOT = KS * 2 * 1024       # bytes of one ring slot
 
@@ -32,7 +43,9 @@ PB = (VB + 154, VB + 155)
 V_SC = VB + 156            # S
 # ring addresses, one set per iteration parity (R2)
 ADDR = {"A": (VB + 157, VB + 158, VB + 159), "B": (VB + 160, VB + 161, VB + 162)}
-V_LAST = VB + 162
+# --direct: byte offsets of the next sample group into the buffer / into the carry
+OFF = {"A": (VB + 163, VB + 164), "B": (VB + 165, VB + 166)}
+V_LAST = VB + 166 if DIRECT else VB + 162
 NVGPR_CLOBBER = list(range(VB, V_LAST + 1))
 NAGPR = 64
 
@@ -48,7 +61,14 @@ S_XB = 52      # s[52:53] x base, block 0
 S_TB = 54      # s[54:55] taps base, block 0
 S_BF = 56      # s[56:57] phasor-table images
 S_PSTRIDE = 58
-SGPR_CLOBBER = list(range(36, 80))
+# --direct
+S_B32 = 59     # 32 * block index of the loads being prepared
+S_SMAX = 72    # L - 4
+S_CL8 = 73     # 8 * carry length
+S_CB = 74      # s[74:75] carry base
+MK = {"A": 80, "B": 82, "C": 84}   # lanes whose group lies in the carry
+S_EXEC = 86    # s[86:87] EXEC on entry
+SGPR_CLOBBER = list(range(36, 88 if DIRECT else 80))
 
 
 def vr(base, n=1):
@@ -138,11 +158,26 @@ def produce_ops(xa=None, xb=None, hv=None):
     return ops
 
 
-def gload_ops(cnt, out, par, xa=None, xb=None, hv=None):
+def gload_ops(cnt, out, par, xa=None, xb=None, hv=None, off=None):
     S_X, S_T = SB[par]["x"], SB[par]["t"]
     xa, xb, hv = (XA if xa is None else xa), (XB if xb is None else xb), (HV if hv is None else hv)
     out.append(f"global_load_dwordx4 {vr(hv, 4)}, %[to], s[{S_T}:{S_T + 1}]")
     cnt.issue_vm("hv")
+    if DIRECT:
+        oi, oc = off if off is not None else OFF[par]
+        mk = MK[par]
+        out.append(f"s_andn2_b64 exec, exec, s[{mk}:{mk + 1}]")
+        out.append(f"global_load_dwordx4 {vr(xa, 4)}, {vr(oi)}, s[{S_XB}:{S_XB + 1}]")
+        cnt.issue_vm("xa")
+        out.append(f"global_load_dwordx4 {vr(xb, 4)}, {vr(oi)}, s[{S_XB}:{S_XB + 1}] offset:16")
+        cnt.issue_vm("xb")
+        out.append(f"s_and_b64 exec, s[{S_EXEC}:{S_EXEC + 1}], s[{mk}:{mk + 1}]")
+        out.append(f"global_load_dwordx4 {vr(xa, 4)}, {vr(oc)}, s[{S_CB}:{S_CB + 1}]")
+        cnt.issue_vm("xa")
+        out.append(f"global_load_dwordx4 {vr(xb, 4)}, {vr(oc)}, s[{S_CB}:{S_CB + 1}] offset:16")
+        cnt.issue_vm("xb")
+        out.append(f"s_mov_b64 exec, s[{S_EXEC}:{S_EXEC + 1}]")
+        return
     out.append(f"global_load_dwordx4 {vr(xa, 4)}, %[xo], s[{S_X}:{S_X + 1}]")
     cnt.issue_vm("xa")
     out.append(f"global_load_dwordx4 {vr(xb, 4)}, %[xo], s[{S_X}:{S_X + 1}] offset:16")
@@ -152,6 +187,15 @@ def gload_ops(cnt, out, par, xa=None, xb=None, hv=None):
 def advance_load_pointers(par):
     """SALU: pointers (parity set `par`) of block min(S_K, nhi-1), then S_K += 1."""
     S_X, S_T = SB[par]["x"], SB[par]["t"]
+    if DIRECT:
+        return [
+            f"s_min_u32 s{S_T0}, s{S_K}, s{S_NHI1}",
+            f"s_lshl_b32 s{S_B32}, s{S_T0}, 5",
+            f"s_lshl_b32 s{S_T1}, s{S_T0}, 7",
+            f"s_add_u32 s{S_T}, s{S_TB}, s{S_T1}",
+            f"s_addc_u32 s{S_T + 1}, s{S_TB + 1}, 0",
+            f"s_add_u32 s{S_K}, s{S_K}, 1",
+        ]
     return [
         f"s_min_u32 s{S_T0}, s{S_K}, s{S_NHI1}",
         f"s_lshl_b32 s{S_T1}, s{S_T0}, 8",
@@ -161,6 +205,21 @@ def advance_load_pointers(par):
         f"s_add_u32 s{S_T}, s{S_TB}, s{S_T1}",
         f"s_addc_u32 s{S_T + 1}, s{S_TB + 1}, 0",
         f"s_add_u32 s{S_K}, s{S_K}, 1",
+    ]
+
+
+def offset_ops(par, off=None):
+    """--direct, VALU: offsets and carry mask (parity set `par`) of the sample group
+    s = s0 + S_B32 (advance_load_pointers ran before)."""
+    oi, oc = off if off is not None else OFF[par]
+    mk = MK[par]
+    return [
+        f"v_add_u32 {vr(oc)}, s{S_B32}, %[s0]",
+        f"v_cmp_gt_i32 s[{mk}:{mk + 1}], 0, {vr(oc)}",
+        f"v_max_i32 {vr(oi)}, 0, {vr(oc)}",
+        f"v_min_i32 {vr(oi)}, s{S_SMAX}, {vr(oi)}",
+        f"v_lshlrev_b32 {vr(oi)}, 3, {vr(oi)}",
+        f"v_lshl_add_u32 {vr(oc)}, {vr(oc)}, 3, s{S_CL8}",
     ]
 
 
@@ -225,6 +284,11 @@ def iteration(cnt, out, cur, prev, p_cur, p_prev, label):
                 gaps[g].append(("prod", prod[pi], None))
                 pi += 1
     assert pi == len(prod), (pi, len(prod))
+    if DIRECT:
+        # offsets of the next iteration's loads: after the conversion's wait (gap 10), which
+        # covers the last loads that read this parity's offset registers
+        for i, op in enumerate(offset_ops(other)):
+            gaps[11 + i].append(("addr", op, None))
 
     gaps[17].append(("ldsw", f"ds_write_b128 {vr(V_WR)}, {vr(HI4, 4)}", "wh"))
     gaps[17].append(("ldsw", f"ds_write_b128 {vr(V_WR)}, {vr(LO4, 4)} offset:1024", "wl"))
@@ -280,6 +344,12 @@ def generate():
     o("; ===== prologue =====")
     o(f"s_mov_b32 s{S_XB}, %[xb_lo]")
     o(f"s_mov_b32 s{S_XB + 1}, %[xb_hi]")
+    if DIRECT:
+        o(f"s_mov_b64 s[{S_EXEC}:{S_EXEC + 1}], exec")
+        o(f"s_mov_b32 s{S_CB}, %[cb_lo]")
+        o(f"s_mov_b32 s{S_CB + 1}, %[cb_hi]")
+        o(f"s_mov_b32 s{S_SMAX}, %[smax]")
+        o(f"s_mov_b32 s{S_CL8}, %[cl8]")
     o(f"s_mov_b32 s{S_TB}, %[tp_lo]")
     o(f"s_mov_b32 s{S_TB + 1}, %[tp_hi]")
     o(f"s_mov_b32 s{SB['A']['p']}, %[pp_lo]")
@@ -316,13 +386,20 @@ def generate():
     # into ring slots 0 and 1, block 2 is moved to the input registers for trip 0
     T1 = (F0, F0 + 4, F0 + 8)          # xa, xb, hv of block 1
     T2 = (F0 + 12, F0 + 16, F0 + 20)   # of block 2
+    OFF_C = (CA[0], CA[0] + 1)          # offsets of block 2: set A is written by the first MFMA only
     out.extend(advance_load_pointers("A"))
+    if DIRECT:
+        out.extend(offset_ops("A"))
     out.extend(advance_load_pointers("B"))
+    if DIRECT:
+        out.extend(offset_ops("B"))
     out.extend(advance_load_pointers("C"))
+    if DIRECT:
+        out.extend(offset_ops("C", OFF_C))
     o("s_nop 4")
     gload_ops(cnt, out, "A")
     gload_ops(cnt, out, "B", *T1)
-    gload_ops(cnt, out, "C", *T2)
+    gload_ops(cnt, out, "C", *T2, off=OFF_C)
     o("s_waitcnt vmcnt(0)")          # the phasor images as well
     cnt.vm = []
     for blk, src in ((0, (None, None, None)), (1, T1)):
@@ -336,6 +413,8 @@ def generate():
         o(f"v_mov_b32 {vr(XB + i)}, {vr(T2[1] + i)}")
         o(f"v_mov_b32 {vr(HV + i)}, {vr(T2[2] + i)}")
     out.extend(advance_load_pointers("A"))   # block 3: iteration 0 ("A") loads it
+    if DIRECT:
+        out.extend(offset_ops("A"))
     V_RD, V_RDN, V_WR = ADDR["A"]
     o(f"v_add_u32 {vr(V_RD)}, s{S_RD}, %[lane16]")
     o(f"v_add_u32 {vr(V_RDN)}, s{S_RDN}, %[lane16]")
@@ -347,7 +426,8 @@ def generate():
     o("s_waitcnt lgkmcnt(0)")
     cnt.lgkm = []
     # steady state entry: vm = [hv, xa, xb]; the loop expects [p_prev, hv, xa, xb]
-    cnt.vm = ["prB", "pB", "hv", "xa", "xb"]
+    XL = ["hv", "xa", "xb", "xa", "xb"] if DIRECT else ["hv", "xa", "xb"]
+    cnt.vm = ["prB", "pB"] + XL
     o("; ===== main loop, two blocks per trip =====")
     o("1:")
     iteration(cnt, out, CA, CB, PA, PB, "A")
@@ -360,8 +440,8 @@ def generate():
     o(f"s_cmp_lg_u32 s{S_NLEFT}, 0")
     o("s_cbranch_scc1 1b")
     if True:
-        assert cnt.lgkm == [] and cnt.vm == ["prB", "pB", "hv", "xa", "xb"], (cnt.lgkm, cnt.vm)
-        assert state_a == ([], ["prA", "pA", "hv", "xa", "xb"]), state_a
+        assert cnt.lgkm == [] and cnt.vm == ["prB", "pB"] + XL, (cnt.lgkm, cnt.vm)
+        assert state_a == ([], ["prA", "pA"] + XL), state_a
     # exits: P*C of the last block
     o("; last block was in set B")
     o("s_waitcnt vmcnt(0)")
@@ -389,12 +469,13 @@ def generate():
 
 def main():
     lines = generate()
-    print("// GENERATED by tools/gen_ddc_mfma_ring.py -- do not edit.")
+    PFX = "GSDR_MFMA_RINGD" if DIRECT else "GSDR_MFMA_RING"
+    print("// GENERATED by tools/gen_ddc_mfma_ring.py%s -- do not edit." % (" --direct" if DIRECT else ""))
     print("// Main loop of ddc_mfma_ring_kernel: see the generator for the schedule and register map.")
     print("#pragma once")
-    print(f"#define GSDR_MFMA_RING_VB {VB}")
-    print(f"#define GSDR_MFMA_RING_BYTES {3 * SLOT}")
-    print("#define GSDR_MFMA_RING_TEXT \\")
+    print(f"#define {PFX}_VB {VB}")
+    print(f"#define {PFX}_BYTES {3 * SLOT}")
+    print(f"#define {PFX}_TEXT \\")
     for ln in lines:
         if ln.startswith(";"):
             continue
@@ -402,7 +483,7 @@ def main():
     print('    ""')
     clob = [f'"v{i}"' for i in NVGPR_CLOBBER] + [f'"a{i}"' for i in range(NAGPR)] + \
            [f'"s{i}"' for i in SGPR_CLOBBER] + ['"vcc"', '"scc"', '"memory"']
-    print("#define GSDR_MFMA_RING_CLOBBERS \\")
+    print(f"#define {PFX}_CLOBBERS \\")
     for i in range(0, len(clob), 12):
         tail = ", \\" if i + 12 < len(clob) else ""
         print("    " + ", ".join(clob[i:i + 12]) + tail)
