@@ -38,6 +38,7 @@ RATE = 200_000_000
 L = 1_000_000
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: FP32 vector == FP32 matrix peak
+PROFILE_EVERY = int(os.environ.get("GSDR_BENCH_PROFILE_EVERY", "8"))   # 0: no kernel timing
 F16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense f16/bf16 MFMA
 
 WORKLOADS = {
@@ -160,29 +161,61 @@ def build_workload(wl, device, seed, ring=8, n_tones=None):
     return dem, bufs, out, N, p
 
 
-def run_steps(dem, bufs, out, steps, stream=None):
+def run_steps(dem, bufs, out, steps, stream=None, k0=0):
     n = 0
-    for k in range(steps):
+    for k in range(k0, k0 + steps):
         n = dem.process_device(bufs[k % len(bufs)], out, stream)
     return n
 
 
+def run_steps_pipelined(dem, bufs, outs, steps, k0=0):
+    """gsdr_demod_submit_device / gsdr_demod_wait: up to len(outs) buffers outstanding, one
+    output buffer each; every submitted buffer is waited for before this returns."""
+    depth, pending = len(outs), 0
+    for k in range(k0, k0 + steps):
+        if pending == depth:
+            dem.wait()
+            pending -= 1
+        dem.submit_device(bufs[k % len(bufs)], outs[k % depth])
+        pending += 1
+    while pending:
+        dem.wait()
+        pending -= 1
+
+
+PIPE_DEPTH = 3
+
+
 def time_workload(wl, device, seed, steps, warmup, dist=None, n_tones=None, profile=True,
-                  ctl_device="same"):
+                  ctl_device="same", api="inorder"):
+    """api "inorder": gsdr_demod_process_device on one stream, step after step.
+    api "pipelined": gsdr_demod_submit_device / gsdr_demod_wait, PIPE_DEPTH outstanding: the
+    kernels of consecutive buffers overlap on the GPU (include/gsdr.h)."""
     import torch
     if ctl_device == "same":
         ctl_device = device
     dem, bufs, out, N, _ = build_workload(wl, device, seed, n_tones=n_tones)
     stream = torch.cuda.Stream(device)  # the hot path runs on its own (non-null) stream
+    outs = [out] + [torch.empty_like(out) for _ in range(PIPE_DEPTH - 1)] if api == "pipelined" else None
+
+    def run(count, k0):
+        if api == "pipelined":
+            run_steps_pipelined(dem, bufs, outs, count, k0)
+        else:
+            run_steps(dem, bufs, out, count, stream, k0)
+
     torch.cuda.synchronize(device)
-    run_steps(dem, bufs, out, warmup, stream)
+    run(warmup, 0)
     torch.cuda.synchronize(device)
+    profile = profile and PROFILE_EVERY > 0
     if profile:
-        dem.profile_enable(True)
+        # hipEvents around every 8th launch of the dominant kernel, inside the timed region
+        # (around every launch they cost ~6 us of stream time per step)
+        dem.profile_enable(PROFILE_EVERY)
     barrier(dist, ctl_device)
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
-    run_steps(dem, bufs, out, steps, stream)
+    run(steps, warmup)
     torch.cuda.synchronize(device)
     t1 = time.perf_counter()
     barrier(dist, ctl_device)
@@ -191,7 +224,7 @@ def time_workload(wl, device, seed, steps, warmup, dist=None, n_tones=None, prof
     kname = dem.kernel_name
     dem.close()
     return dict(elapsed=elapsed, local_elapsed=t1 - t0, kernel_launches=kn, kernel_ms=kms,
-                kernel=kname, n_tones=N)
+                kernel=kname, n_tones=N, api=api)
 
 
 def max_realtime_tones(device, seed, budget_s=60.0):
@@ -203,7 +236,7 @@ def max_realtime_tones(device, seed, budget_s=60.0):
     lo, hi = 2048, None
     n = 2048
     while time.perf_counter() - t_start < budget_s:
-        r = time_workload(wl, device, seed, steps=200, warmup=5, n_tones=n, profile=False)
+        r = time_workload(wl, device, seed, steps=200, warmup=5, n_tones=n, profile=False, api="pipelined")
         msps = 200 * L / r["elapsed"] / 1e6
         probes.append((n, round(msps, 1)))
         if msps >= 200.0:
@@ -290,6 +323,42 @@ def recorded_traffic(workload: str):
         return None
 
 
+def rooflines(wl, r, key):
+    """(roofline of the bounding pipe, HBM roofline) of the dominant kernel from the hipEvent
+    durations time_workload() collected; (None, None) without them."""
+    ab, af = algorithmic(wl, r["n_tones"])
+    kt = (r["kernel_ms"] / r["kernel_launches"] * 1e-3) if r["kernel_launches"] else None
+    if not kt:
+        return None, None
+    gbs = ab * L / kt / 1e9
+    tfl = af * L / kt / 1e12
+    traffic = recorded_traffic(key)
+    roof_hbm = dict(bound="hbm", achieved=round(gbs, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(gbs / HBM_PEAK_GBS, 5), traffic=traffic,
+                    kernel=r["kernel"], kernel_us=round(kt * 1e6, 2))
+    if wl["kind"] in ("direct", "pfb") and r["kernel"].startswith("ddc_mfma"):
+        # matrix-core DDC: every (tone, sample, tap phase) is one complex MAC done as
+        # three fp16 x fp16 -> fp32 products of a hi/lo split: 3 * 4 real MACs = 24 flop
+        # on the f16 MFMA pipe (DESIGN.md section 4); peak = dense f16 MFMA.
+        mf = 24.0 * wl["pf_average"] * r["n_tones"]
+        mtfl = mf * L / kt / 1e12
+        roof = dict(bound="mfma", pipe="f16 MFMA, fp32 accumulate, 3-product hi/lo split of fp32 operands",
+                    achieved=round(mtfl, 1), peak=F16_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=round(mtfl / F16_MFMA_PEAK_TFLOPS, 4), traffic=traffic,
+                    fp32_equivalent_tflops=round(tfl, 1),
+                    kernel=r["kernel"], kernel_us=round(kt * 1e6, 2))
+    elif wl["kind"] in ("direct", "pfb"):
+        # packed-FP32 DDC (GSDR_DDC_MFMA=0): FP32-compute bound (SURVEY.md 8d). The FP32
+        # vector peak equals the FP32 (f32-input) MFMA peak on gfx950: 157.3 TF.
+        roof = dict(bound="mfma", pipe="fp32 valu (no MFMA used; same 157.3 TF peak)",
+                    achieved=round(tfl, 3), peak=FP32_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=round(tfl / FP32_PEAK_TFLOPS, 4), traffic=traffic,
+                    kernel=r["kernel"], kernel_us=round(kt * 1e6, 2))
+    else:
+        roof = roof_hbm
+    return roof, roof_hbm
+
+
 # --------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
@@ -297,6 +366,8 @@ def main():
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--api", default="auto", choices=["auto", "inorder", "pipelined"],
+                    help="entry the timed steps go through; auto = pipelined for the DDC (DIRECT) workloads")
     ap.add_argument("--no-extras", action="store_true", help="skip c3/c4/max-tone extras")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     args = ap.parse_args()
@@ -325,41 +396,25 @@ def main():
 
     wl = WORKLOADS[args.workload]
     seed = stream_seed(rank)
-    r = time_workload(wl, device, seed, args.steps, args.warmup, dist, ctl_device=ctl_device)
+    api = args.api if args.api != "auto" else ("pipelined" if wl["kind"] == "direct" else "inorder")
+    r = time_workload(wl, device, seed, args.steps, args.warmup, dist, ctl_device=ctl_device, api=api)
     samples_total = args.steps * L * world
     value = samples_total / r["elapsed"] / 1e6
     ms_per_step = r["elapsed"] / args.steps * 1e3
 
-    ab, af = algorithmic(wl, r["n_tones"])
-    kt = (r["kernel_ms"] / r["kernel_launches"] * 1e-3) if r["kernel_launches"] else None
-    roof_hbm = roof = None
-    if kt:
-        gbs = ab * L / kt / 1e9
-        tfl = af * L / kt / 1e12
-        traffic = recorded_traffic(args.workload)
-        roof_hbm = dict(bound="hbm", achieved=round(gbs, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(gbs / HBM_PEAK_GBS, 5), traffic=traffic,
-                        kernel=r["kernel"], kernel_us=round(kt * 1e6, 2))
-        if wl["kind"] in ("direct", "pfb") and r["kernel"].startswith("ddc_mfma"):
-            # matrix-core DDC: every (tone, sample, tap phase) is one complex MAC done as
-            # three fp16 x fp16 -> fp32 products of a hi/lo split: 3 * 4 real MACs = 24 flop
-            # on the f16 MFMA pipe; peak = dense f16 MFMA.
-            mf = 24.0 * wl["pf_average"] * r["n_tones"]
-            mtfl = mf * L / kt / 1e12
-            roof = dict(bound="mfma", pipe="f16 MFMA, fp32 accumulate, 3-product hi/lo split of fp32 operands",
-                        achieved=round(mtfl, 1), peak=F16_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=round(mtfl / F16_MFMA_PEAK_TFLOPS, 4), traffic=traffic,
-                        fp32_equivalent_tflops=round(tfl, 1),
-                        kernel=r["kernel"], kernel_us=round(kt * 1e6, 2))
-        elif wl["kind"] in ("direct", "pfb"):
-            # packed-FP32 DDC (GSDR_DDC_MFMA=0): FP32-compute bound. The FP32
-            # vector peak equals the FP32 (f32-input) MFMA peak on gfx950: 157.3 TF.
-            roof = dict(bound="mfma", pipe="fp32 valu (no MFMA used; same 157.3 TF peak)",
-                        achieved=round(tfl, 3), peak=FP32_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=round(tfl / FP32_PEAK_TFLOPS, 4), traffic=traffic,
-                        kernel=r["kernel"], kernel_us=round(kt * 1e6, 2))
-        else:
-            roof = roof_hbm
+    roof, roof_hbm = rooflines(wl, r, args.workload)
+    inorder = None
+    if api == "pipelined" and not args.no_extras:
+        # the same kernel with the GPU to itself: the in-order entry, one stream, same K steps
+        ra = time_workload(wl, device, seed, args.steps, args.warmup, None, api="inorder")
+        alone, _ = rooflines(wl, ra, args.workload)
+        inorder = dict(api="gsdr_demod_process_device, one stream",
+                       value=round(args.steps * L / ra["local_elapsed"] / 1e6, 2), unit="Msamples/s per GPU",
+                       ms_per_step=round(ra["local_elapsed"] / args.steps * 1e3, 5))
+        if roof and alone:
+            roof["note"] = ("launch durations of the timed region: launches of consecutive buffers overlap there "
+                            "and share the chip; 'alone' is the same kernel in the in-order pass of this run")
+            roof["alone"] = {k: alone[k] for k in ("achieved", "frac", "kernel_us")}
 
     line = {
         "metric": "IQ Msamples/s ingested (one synthetic 200 Msps stream per GPU)",
@@ -368,10 +423,14 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": wl["name"], "key": args.workload, "buffer_len": L,
                    "rate": wl.get("rate", RATE), "tones_per_stream": r["n_tones"],
-                   "streams": world, "parallelism": f"{world} independent stream(s), one per GPU, no collective"},
+                   "streams": world, "parallelism": f"{world} independent stream(s), one per GPU, no collective",
+                   "api": ("gsdr_demod_submit_device/gsdr_demod_wait, %d buffers outstanding" % PIPE_DEPTH)
+                          if api == "pipelined" else "gsdr_demod_process_device, one stream"},
         "realtime_factor": round(value / world / (wl.get("rate", RATE) / 1e6), 3),
         "roofline": roof, "roofline_hbm": roof_hbm,
     }
+    if inorder:
+        line["inorder"] = inorder
 
     if world == 1 and rank == 0:
         if not args.no_extras:
@@ -379,10 +438,11 @@ def main():
             for key in ("c3", "c4"):
                 if key == args.workload:
                     continue
-                e = time_workload(WORKLOADS[key], device, seed, steps=100, warmup=5)
+                e = time_workload(WORKLOADS[key], device, seed, steps=100, warmup=5,
+                                  api="pipelined" if WORKLOADS[key]["kind"] == "direct" else "inorder")
                 eb, ef = algorithmic(WORKLOADS[key], e["n_tones"])
                 ekt = e["kernel_ms"] / max(e["kernel_launches"], 1) * 1e-3
-                extras[key] = dict(msamples_per_s=round(100 * L / e["elapsed"] / 1e6, 2),
+                extras[key] = dict(msamples_per_s=round(100 * L / e["elapsed"] / 1e6, 2), api=e["api"],
                                    kernel=e["kernel"], kernel_us=round(ekt * 1e6, 2),
                                    hbm_gbs=round(eb * L / ekt / 1e9, 2),
                                    fp32_equivalent_tflops=round(ef * L / ekt / 1e12, 3))

@@ -57,8 +57,8 @@ struct gsdr_demod {
     // pipelined host-pointer entry (gsdr_demod_submit / _wait)
     struct Slot {
         float2 *d_in = nullptr, *d_out = nullptr;
-        gsdr_c64 *out_host = nullptr;
         hipEvent_t up = nullptr, done = nullptr, down = nullptr;
+        hipEvent_t wait_ev = nullptr;      // what gsdr_demod_wait() waits for: down (host) / done (device)
         int n = 0;
     } slot[GSDR_PIPELINE_DEPTH];
     hipStream_t s_up = nullptr, s_down = nullptr;
@@ -97,9 +97,16 @@ struct gsdr_demod {
     float2 *d_ptab = nullptr, *d_dtab = nullptr;
     float *d_mtaps = nullptr;
     unsigned *d_mfmod = nullptr, *d_maxbits = nullptr;
-    float2 *d_head[2] = {nullptr, nullptr};     // [carry | first rows' samples | zeros], see absmax_kernel
-    float2 *d_tail = nullptr;                   // [last rows' samples | zeros]
-    int xparity = 0;
+    // [carry | first rows' samples | zeros] and [last rows' samples | zeros], see absmax_kernel.
+    // Three of each, used in turn: the staging pass of call j writes set j%3 (and the carry
+    // part of head (j+1)%3) while the main kernel of call j-1 may still read set (j-1)%3.
+    float2 *d_head[3] = {nullptr, nullptr, nullptr};
+    float2 *d_tail[3] = {nullptr, nullptr, nullptr};
+    // pipelined entries (gsdr_demod_submit*): consecutive DIRECT calls go to two compute
+    // streams in turn, so that their kernels overlap (see pipeline_compute)
+    hipStream_t s_main[2] = {nullptr, nullptr};
+    hipEvent_t ev_abs[4] = {nullptr, nullptr, nullptr, nullptr};    // staging pass of call j done
+    bool pipe_overlap = false;         // set around the compute of an overlapped call
     unsigned long long call_no = 0;    // absmax slot rotation
     // ---- TONES ----
     std::vector<int> bins;
@@ -118,6 +125,8 @@ struct gsdr_demod {
 
     // ---- profiling ----
     bool prof = false;
+    int prof_every = 1;                // time every n-th launch (an event pair costs ~3 us of stream time)
+    unsigned long long prof_seen = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
     const char *kernel_name = "none";
@@ -376,8 +385,8 @@ int setup_mfma(gsdr_demod *h, bool direct, const std::vector<long long> &tone) {
     HIPCHK(h, upload(&h->d_dtab, dtab));
     HIPCHK(h, upload(&h->d_mtaps, taps));
     HIPCHK(h, upload(&h->d_mfmod, fmod));
-    HIPCHK(h, dev_alloc(&h->d_maxbits, 3 * 16));   // three slots of 16 partial maxima
-    HIPCHK(h, hipMemset(h->d_maxbits, 0, 3 * 16 * sizeof(unsigned)));
+    HIPCHK(h, dev_alloc(&h->d_maxbits, 4 * 16));   // four slots of 16 partial maxima
+    HIPCHK(h, hipMemset(h->d_maxbits, 0, 4 * 16 * sizeof(unsigned)));
     gsdr::MfmaShape &sh = h->mf;
     sh.N = h->ddc_channels;
     sh.NT32 = pl.ntg * pl.TT;
@@ -400,12 +409,12 @@ int setup_mfma(gsdr_demod *h, bool direct, const std::vector<long long> &tone) {
         const size_t reach = (size_t)((pl.nk8 + pl.PK / 8 - 1) / (pl.PK / 8)) * pl.PK;   // whole phasor blocks
         const size_t head_n = (size_t)sh.carry_len + 32u * (size_t)M + reach + 8;
         const size_t tail_n = (size_t)(32 + F) * (size_t)M + reach + 8;
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 3; ++i) {
             HIPCHK(h, dev_alloc(&h->d_head[i], head_n));
             HIPCHK(h, hipMemset(h->d_head[i], 0, head_n * sizeof(float2)));
+            HIPCHK(h, dev_alloc(&h->d_tail[i], tail_n));
+            HIPCHK(h, hipMemset(h->d_tail[i], 0, tail_n * sizeof(float2)));
         }
-        HIPCHK(h, dev_alloc(&h->d_tail, tail_n));
-        HIPCHK(h, hipMemset(h->d_tail, 0, tail_n * sizeof(float2)));
     }
     h->mfma = true;
     h->kernel_name = gsdr::ddc_mfma_kernel_name(h->mf_kind);
@@ -421,6 +430,7 @@ int enqueue_mfma(gsdr_demod *h, const float2 *in, float2 *raw, long long raw_new
 int record_begin(gsdr_demod *h, hipStream_t st, hipEvent_t *stop) {
     *stop = nullptr;
     if (!h->prof || h->ev_used >= (size_t)kMaxEvents) return 0;
+    if (h->prof_seen++ % (unsigned long long)h->prof_every != 0) return 0;
     if (h->ev_used == h->ev_pool.size()) {
         hipEvent_t a, b;
         HIPCHK(h, hipEventCreate(&a));
@@ -518,8 +528,12 @@ int autotune_chunks(gsdr_demod *h, int nblk) {
 
 int enqueue_mfma(gsdr_demod *h, const float2 *in, float2 *raw, long long raw_new0, long long nx,
                  int nout, unsigned idx_base, float2 *out, hipStream_t st) {
-    const int cur = (int)(h->call_no % 3), prev = (int)((h->call_no + 2) % 3),
-              next = (int)((h->call_no + 1) % 3);
+    // slots: this buffer, the previous one, the one the staging pass clears for the next call.
+    // Four, so that the pass of call j+1 (clearing slot j+2) leaves alone what the main kernel
+    // of call j still reads (slots j and j-1) when the two overlap.
+    const int cur = (int)(h->call_no % 4), prev = (int)((h->call_no + 3) % 4),
+              next = (int)((h->call_no + 1) % 4);
+    const int hs = (int)(h->call_no % 3), hs_next = (int)((h->call_no + 1) % 3);
     gsdr::MfmaLaunch a{};
     a.sh = h->mf;
     a.sh.nout = nout;
@@ -538,23 +552,22 @@ int enqueue_mfma(gsdr_demod *h, const float2 *in, float2 *raw, long long raw_new
     } else if (h->mf_kind == gsdr::MfmaKernel::AsmRingDirect) {
         // single launch: d_head[] only hold the carry (their first carry_len samples)
         a.x = a.tail = in;
-        a.head = h->d_head[h->xparity];
-        a.carry_out = h->d_head[h->xparity ^ 1];
+        a.head = h->d_head[hs];
+        a.carry_out = h->d_head[hs_next];
         a.sh.tail0 = 0;
-        h->xparity ^= 1;
     } else {
         const int cl = a.sh.carry_len;
         const long long t0 = a.sh.ngt > 1 ? (long long)(32 * (a.sh.ngt - 1) + a.sh.woff) * a.sh.M : h->L;
         const int ks = h->mf_PK / 8;
         long long head_n = 32LL * a.sh.M + (long long)((a.sh.nk8 + ks - 1) / ks) * h->mf_PK + 8;
         if (head_n > h->L) head_n = h->L;
-        HIPCHK(h, gsdr::launch_absmax(in, h->L, h->d_maxbits, cur, next, h->d_head[h->xparity], head_n,
-                                      h->d_head[h->xparity ^ 1], cl, h->d_tail, t0, st));
+        HIPCHK(h, gsdr::launch_absmax(in, h->L, h->d_maxbits, cur, next, h->d_head[hs], head_n,
+                                      h->d_head[hs_next], cl, h->d_tail[hs], t0, st));
+        if (h->pipe_overlap) HIPCHK(h, hipEventRecord(h->ev_abs[h->call_no % 4], st));
         a.x = in;
-        a.head = h->d_head[h->xparity];
-        a.tail = h->d_tail;
+        a.head = h->d_head[hs];
+        a.tail = h->d_tail[hs];
         a.sh.tail0 = t0;
-        h->xparity ^= 1;
     }
     a.taps = h->d_mtaps;
     a.bfrag = h->d_bfrag;
@@ -1016,6 +1029,58 @@ int gsdr_demod_process(gsdr_demod *h, const gsdr_c64 *in_host, gsdr_c64 *out_hos
     return ret;
 }
 
+// streams and events of the pipelined entries, created on first use
+static int pipeline_init(gsdr_demod *h) {
+    if (h->s_up) return 0;
+    HIPCHK(h, hipStreamCreateWithFlags(&h->s_up, hipStreamNonBlocking));
+    HIPCHK(h, hipStreamCreateWithFlags(&h->s_down, hipStreamNonBlocking));
+    for (auto &sl : h->slot) {
+        HIPCHK(h, hipEventCreateWithFlags(&sl.up, hipEventDisableTiming));
+        HIPCHK(h, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        HIPCHK(h, hipEventCreateWithFlags(&sl.down, hipEventDisableTiming));
+    }
+    // The two compute streams must sit on different hardware queues to overlap.  HIP deals the
+    // streams of one priority class out to few queues (4 by default) that every other stream
+    // of that class in the process shares too (torch alone creates dozens): which two streams
+    // end up together is luck.  The low-priority class is ours alone, and low priority is what
+    // the reference gives its demodulator stream (cpp/USRP_demodulator.cpp:44).
+    int prio_least = 0, prio_greatest = 0;
+    HIPCHK(h, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    for (int i = 0; i < 2; ++i)
+        HIPCHK(h, hipStreamCreateWithPriority(&h->s_main[i], hipStreamNonBlocking, prio_least));
+    for (int i = 0; i < 4; ++i) HIPCHK(h, hipEventCreateWithFlags(&h->ev_abs[i], hipEventDisableTiming));
+    return 0;
+}
+
+// The kernels of one pipelined buffer; records sl.done behind them.  `up`: event the input
+// becomes ready with (nullptr: it is ready).
+//
+// DIRECT on the staged matrix-core kernel: call j runs on compute stream j & 1, so the
+// kernels of consecutive buffers overlap and the next buffer fills the compute units that
+// the last workgroups of this one leave idle.  What call j needs from its neighbours:
+//   - its staging pass follows the pass of call j-1 (which wrote the carry in front of this
+//     call's head copy and cleared this call's scale slot): one event, long complete when
+//     it is waited for;
+//   - everything it overwrites was last read by the main kernels of calls j-2 (same stream)
+//     and j-3 (in front of pass j-1 on the other stream); the main kernel of call j-1 reads
+//     head/tail set (j-1)%3 and slots j-1, j-2, the pass of call j writes head/tail set j%3,
+//     the carry part of head (j+1)%3, slot j and clears slot j+1 (mod 4): disjoint.
+// Every other mode keeps the one compute stream.  GSDR_PIPE_OVERLAP=0 does so for DIRECT too.
+static int pipeline_compute(gsdr_demod *h, gsdr_demod::Slot &sl, hipEvent_t up, const float2 *in, float2 *out) {
+    const bool overlap = env_int("GSDR_PIPE_OVERLAP", 1) != 0 && h->mfma && h->mode == GSDR_DIRECT &&
+                         h->decim > 0 && h->mf_kind != gsdr::MfmaKernel::AsmRingDirect;
+    hipStream_t cs = overlap ? h->s_main[h->call_no & 1] : h->stream;
+    if (up) HIPCHK(h, hipStreamWaitEvent(cs, up, 0));
+    if (overlap && h->call_no > 0) HIPCHK(h, hipStreamWaitEvent(cs, h->ev_abs[(h->call_no - 1) % 4], 0));
+    h->pipe_overlap = overlap;
+    const int n = gsdr_demod_process_device(h, reinterpret_cast<const gsdr_c64 *>(in),
+                                            reinterpret_cast<gsdr_c64 *>(out), cs);
+    h->pipe_overlap = false;
+    if (n < 0) return -1;
+    HIPCHK(h, hipEventRecord(sl.done, cs));
+    return n;
+}
+
 int gsdr_demod_submit(gsdr_demod *h, const gsdr_c64 *in_host, gsdr_c64 *out_host) {
     if (!h) return -1;
     if (!in_host || !out_host) {
@@ -1027,31 +1092,44 @@ int gsdr_demod_submit(gsdr_demod *h, const gsdr_c64 *in_host, gsdr_c64 *out_host
         return -1;
     }
     if (h->device >= 0) HIPCHK(h, hipSetDevice(h->device));
-    if (!h->s_up) {
-        HIPCHK(h, hipStreamCreateWithFlags(&h->s_up, hipStreamNonBlocking));
-        HIPCHK(h, hipStreamCreateWithFlags(&h->s_down, hipStreamNonBlocking));
-        for (auto &sl : h->slot) {
-            HIPCHK(h, dev_alloc(&sl.d_in, (size_t)h->L));
-            HIPCHK(h, dev_alloc(&sl.d_out, (size_t)h->capacity));
-            HIPCHK(h, hipEventCreateWithFlags(&sl.up, hipEventDisableTiming));
-            HIPCHK(h, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
-            HIPCHK(h, hipEventCreateWithFlags(&sl.down, hipEventDisableTiming));
-        }
-    }
+    if (pipeline_init(h)) return -1;
     auto &sl = h->slot[(h->pipe_head + h->pipe_count) % GSDR_PIPELINE_DEPTH];
+    if (!sl.d_in) {
+        HIPCHK(h, dev_alloc(&sl.d_in, (size_t)h->L));
+        HIPCHK(h, dev_alloc(&sl.d_out, (size_t)h->capacity));
+    }
     // the slot is free: its previous download was waited for in gsdr_demod_wait()
     HIPCHK(h, hipMemcpyAsync(sl.d_in, in_host, (size_t)h->L * sizeof(float2), hipMemcpyHostToDevice, h->s_up));
     HIPCHK(h, hipEventRecord(sl.up, h->s_up));
-    HIPCHK(h, hipStreamWaitEvent(h->stream, sl.up, 0));
-    const int n = gsdr_demod_process_device(h, reinterpret_cast<gsdr_c64 *>(sl.d_in),
-                                            reinterpret_cast<gsdr_c64 *>(sl.d_out), h->stream);
+    const int n = pipeline_compute(h, sl, sl.up, sl.d_in, sl.d_out);
     if (n < 0) return -1;
-    HIPCHK(h, hipEventRecord(sl.done, h->stream));
     HIPCHK(h, hipStreamWaitEvent(h->s_down, sl.done, 0));
     if (n > 0)
         HIPCHK(h, hipMemcpyAsync(out_host, sl.d_out, (size_t)n * sizeof(float2), hipMemcpyDeviceToHost, h->s_down));
     HIPCHK(h, hipEventRecord(sl.down, h->s_down));
-    sl.out_host = out_host;
+    sl.wait_ev = sl.down;
+    sl.n = n;
+    h->pipe_count++;
+    return 0;
+}
+
+int gsdr_demod_submit_device(gsdr_demod *h, const gsdr_c64 *in_dev, gsdr_c64 *out_dev) {
+    if (!h) return -1;
+    if (!in_dev || !out_dev) {
+        h->err = "null buffer";
+        return -1;
+    }
+    if (h->pipe_count >= GSDR_PIPELINE_DEPTH) {
+        h->err = "pipeline full: call gsdr_demod_wait() first";
+        return -1;
+    }
+    if (h->device >= 0) HIPCHK(h, hipSetDevice(h->device));
+    if (pipeline_init(h)) return -1;
+    auto &sl = h->slot[(h->pipe_head + h->pipe_count) % GSDR_PIPELINE_DEPTH];
+    const int n = pipeline_compute(h, sl, nullptr, reinterpret_cast<const float2 *>(in_dev),
+                                   reinterpret_cast<float2 *>(out_dev));
+    if (n < 0) return -1;
+    sl.wait_ev = sl.done;
     sl.n = n;
     h->pipe_count++;
     return 0;
@@ -1062,7 +1140,7 @@ int gsdr_demod_wait(gsdr_demod *h) {
     if (h->pipe_count == 0) return -2;
     if (h->device >= 0) HIPCHK(h, hipSetDevice(h->device));
     auto &sl = h->slot[h->pipe_head];
-    HIPCHK(h, hipEventSynchronize(sl.down));
+    HIPCHK(h, hipEventSynchronize(sl.wait_ev));
     h->pipe_head = (h->pipe_head + 1) % GSDR_PIPELINE_DEPTH;
     h->pipe_count--;
     return sl.n;
@@ -1072,6 +1150,8 @@ void gsdr_demod_close(gsdr_demod *h) {
     if (!h) return;
     if (h->device >= 0) (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (int i = 0; i < 2; ++i)
+        if (h->s_main[i]) (void)hipStreamSynchronize(h->s_main[i]);
     if (h->s_up) (void)hipStreamSynchronize(h->s_up);
     if (h->s_down) (void)hipStreamSynchronize(h->s_down);
     for (auto &sl : h->slot) {
@@ -1081,6 +1161,10 @@ void gsdr_demod_close(gsdr_demod *h) {
         if (sl.done) (void)hipEventDestroy(sl.done);
         if (sl.down) (void)hipEventDestroy(sl.down);
     }
+    for (int i = 0; i < 2; ++i)
+        if (h->s_main[i]) (void)hipStreamDestroy(h->s_main[i]);
+    for (int i = 0; i < 4; ++i)
+        if (h->ev_abs[i]) (void)hipEventDestroy(h->ev_abs[i]);
     if (h->s_up) (void)hipStreamDestroy(h->s_up);
     if (h->s_down) (void)hipStreamDestroy(h->s_down);
     for (auto &e : h->ev_pool) {
@@ -1091,7 +1175,8 @@ void gsdr_demod_close(gsdr_demod *h) {
                     h->d_wrem,    h->d_fmod,    h->d_tails,    h->d_carry[0], h->d_carry[1],
                     h->d_raw,     h->d_profile, h->d_ccarry[0], h->d_ccarry[1],
                     h->d_bfrag,   h->d_ptab,    h->d_dtab,     h->d_mtaps,    h->d_mfmod,
-                    h->d_maxbits, h->d_head[0], h->d_head[1], h->d_tail};
+                    h->d_maxbits, h->d_head[0], h->d_head[1], h->d_head[2],
+                    h->d_tail[0], h->d_tail[1], h->d_tail[2]};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);  // ref: 03_implement.md:58-63
@@ -1122,6 +1207,8 @@ int gsdr_demod_get_bins(const gsdr_demod *h, int *bins, int cap) {
 void gsdr_demod_profile_enable(gsdr_demod *h, int enable) {
     if (!h) return;
     h->prof = enable != 0;
+    h->prof_every = enable > 1 ? enable : 1;
+    h->prof_seen = 0;
     h->ev_used = 0;
 }
 

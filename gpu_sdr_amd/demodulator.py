@@ -227,6 +227,20 @@ class RX_buffer_demodulator:
         if self._L.gsdr_demod_submit(self._h, in_buffer.ctypes.data, out_buffer.ctypes.data) != 0:
             raise GsdrError(self._L.gsdr_last_error(self._h).decode())
 
+    def submit_device(self, in_tensor, out_tensor) -> None:
+        """Pipelined device-pointer entry (gsdr_demod_submit_device): in_tensor must be
+        complete (synchronise its producer first), out_tensor distinct per outstanding call."""
+        import torch
+        if not self._h:
+            raise GsdrError("demodulator is closed")
+        for t in (in_tensor, out_tensor):
+            if not (t.is_cuda and t.dtype == torch.complex64 and t.is_contiguous()):
+                raise TypeError("need contiguous complex64 CUDA tensors")
+        if in_tensor.numel() < self.parameters.buffer_len or out_tensor.numel() < self.out_capacity:
+            raise ValueError("tensor too small")
+        if self._L.gsdr_demod_submit_device(self._h, in_tensor.data_ptr(), out_tensor.data_ptr()) != 0:
+            raise GsdrError(self._L.gsdr_last_error(self._h).decode())
+
     def wait(self) -> int:
         """Valid length of the oldest submitted buffer (gsdr_demod_wait)."""
         n = self._L.gsdr_demod_wait(self._h)
@@ -242,8 +256,9 @@ class RX_buffer_demodulator:
             self._h = None
 
     # -- kernel timing (hipEvents on the launch stream) ----------------------
-    def profile_enable(self, on: bool = True) -> None:
-        self._L.gsdr_demod_profile_enable(self._h, 1 if on else 0)
+    def profile_enable(self, on=True) -> None:
+        """on = True / 1: time every launch; an integer n > 1: every n-th launch."""
+        self._L.gsdr_demod_profile_enable(self._h, int(on))
 
     def profile_read(self):
         ms = C.c_double(0.0)

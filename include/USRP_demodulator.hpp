@@ -152,6 +152,11 @@ class RX_buffer_demodulator {
         return gsdr_demod_submit(handle_, reinterpret_cast<const gsdr_c64*>(*in),
                                  reinterpret_cast<gsdr_c64*>(*out)) == 0;
     }
+    //! the same for device-resident buffers (gsdr_demod_submit_device)
+    bool submit_device(const float2* in_dev, float2* out_dev) {
+        return gsdr_demod_submit_device(handle_, reinterpret_cast<const gsdr_c64*>(in_dev),
+                                        reinterpret_cast<gsdr_c64*>(out_dev)) == 0;
+    }
     int wait() {
         const int n = gsdr_demod_wait(handle_);
         if (n == -1) std::fprintf(stderr, "ERROR: demodulator: %s\n", gsdr_last_error(handle_));

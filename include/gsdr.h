@@ -95,9 +95,16 @@ int gsdr_demod_process_device(gsdr_demod *h, const gsdr_c64 *in_dev,
  * out_host must stay valid until that wait returns and should be pinned
  * (hipHostMalloc), otherwise the copies degrade to synchronous ones.
  * Do not mix with gsdr_demod_process() while buffers are outstanding. */
-#define GSDR_PIPELINE_DEPTH 3
+#define GSDR_PIPELINE_DEPTH 4
 int gsdr_demod_submit(gsdr_demod *h, const gsdr_c64 *in_host, gsdr_c64 *out_host);
 int gsdr_demod_wait(gsdr_demod *h);
+/* The same pipeline for a device-resident source (a synthetic generator, a GPU-direct
+ * receiver): in_dev must be complete when the call is made, out_dev must be a different
+ * buffer for every outstanding call; gsdr_demod_wait() returns when out_dev is complete.
+ * Both submit entries run the DIRECT kernels of consecutive buffers on two streams in
+ * turn: the next buffer starts on the compute units the last workgroups of this one
+ * leave idle (GSDR_PIPE_OVERLAP=0: strictly one after the other). */
+int gsdr_demod_submit_device(gsdr_demod *h, const gsdr_c64 *in_dev, gsdr_c64 *out_dev);
 
 /* ref: RX_buffer_demodulator::close, cpp/USRP_demodulator.cpp:333 (+ :466-698).
  * Frees every device allocation and the stream, then the handle itself. */
@@ -125,7 +132,9 @@ int gsdr_demod_get_window(const gsdr_demod *h, float *w, int cap);
 int gsdr_demod_get_bins(const gsdr_demod *h, int *bins, int cap);
 
 /* Per-kernel device timing of the dominant kernel with hipEvents recorded on
- * the launch stream.  enable != 0 starts a fresh accumulation. */
+ * the launch stream.  enable != 0 starts a fresh accumulation; enable = n > 1
+ * times every n-th launch only (a pair of events costs a few microseconds of
+ * stream time, which a throughput measurement should not carry on every step). */
 void gsdr_demod_profile_enable(gsdr_demod *h, int enable);
 /* Synchronises the recorded events; returns the number of timed launches and
  * their summed duration in milliseconds. */

@@ -672,6 +672,75 @@ def test_pipelined_submit_wait_equals_process(cuda_device, gsdr_lib):
         b.close()
 
 
+@pytest.mark.parametrize("overlap", ["1", "0"])
+def test_pipelined_submit_device_overlapping_buffers(cuda_device, gsdr_lib, oracle_mod, monkeypatch, overlap):
+    """gsdr_demod_submit_device: the main kernels of consecutive DIRECT buffers run on two
+    streams and overlap (the staging passes stay in order).  Buffers of very different
+    loudness follow each other, so a kernel that picked up its neighbour's scale slot, head
+    or tail copy would be far off.  Bit-equal to the in-order entry, and within tolerance
+    of the oracle."""
+    import torch
+    monkeypatch.setenv("GSDR_DDC_MFMA", "1")
+    monkeypatch.setenv("GSDR_MFMA_ASM", "2")
+    monkeypatch.setenv("GSDR_PIPE_OVERLAP", overlap)
+    N, rate, M, F, L = 256, 10_000_000, 100, 4, 200_000
+    rng = np.random.default_rng(314)
+    freq = rng.choice(np.arange(-rate // 2 + 1, rate // 2), size=N, replace=False)
+    a, b = make_direct(freq, rate, M, F, L), make_direct(freq, rate, M, F, L)
+    assert b.kernel_name == "ddc_mfma_ring_kernel"
+    ref = oracle_mod.Direct(freq, rate, M, F, L)
+    scales = [1.0, 1e-4, 30.0, 1.0, 1e-3, 1e-3, 100.0, 1.0, 1.0, 1e-2, 5.0]
+    xs = [torch.from_numpy((crandn(rng, L) * np.float32(sc)).astype(np.complex64)).to(cuda_device) for sc in scales]
+    want = []
+    out_a = torch.empty(a.out_capacity, dtype=torch.complex64, device=cuda_device)
+    for x in xs:
+        n = a.process_device(x, out_a)
+        torch.cuda.synchronize()
+        want.append(out_a[:n].cpu().numpy())
+    outs = [torch.zeros(b.out_capacity, dtype=torch.complex64, device=cuda_device) for _ in xs]
+    torch.cuda.synchronize()
+    got, pending = [], []
+    for k, x in enumerate(xs):
+        if len(pending) == 3:
+            j = pending.pop(0)
+            got.append(outs[j][:b.wait()].cpu().numpy())
+        b.submit_device(x, outs[k])
+        pending.append(k)
+    while pending:
+        j = pending.pop(0)
+        got.append(outs[j][:b.wait()].cpu().numpy())
+    assert len(got) == len(want)
+    for k, (y, yr) in enumerate(zip(got, want)):
+        np.testing.assert_array_equal(y, yr, err_msg="buffer %d" % k)
+    for k, x in enumerate(xs[:4]):
+        yo = ref.process(x.cpu().numpy())
+        den = np.linalg.norm(yo, axis=0)
+        err = np.linalg.norm(got[k].reshape(-1, N) - yo, axis=0) / den
+        assert err.max() <= TOL, (k, err.max())
+    # the in-order entry keeps working on the same handle once the pipeline is drained
+    n = b.process_device(xs[0], outs[0])
+    torch.cuda.synchronize()
+    assert n == N * (L // M)
+    a.close()
+    b.close()
+
+
+def test_profile_sampling(cuda_device, gsdr_lib):
+    """gsdr_demod_profile_enable(n): hipEvents around every n-th launch of the dominant kernel."""
+    import torch
+    dem = make_direct([1000, -2500, 77777], 1_000_000, 100, 4, 20_000)
+    x = torch.zeros(20_000, dtype=torch.complex64, device=cuda_device)
+    out = torch.empty(dem.out_capacity, dtype=torch.complex64, device=cuda_device)
+    for every, want in ((1, 16), (True, 16), (4, 4), (8, 2)):
+        dem.profile_enable(every)
+        for _ in range(16):
+            dem.process_device(x, out)
+        torch.cuda.synchronize()
+        n, ms = dem.profile_read()
+        assert n == want and ms > 0
+    dem.close()
+
+
 def test_sw_loop_tx_tones_into_rx_direct(cuda_device, gsdr_lib):
     """The reference's --sw_loop chain: TX_buffer_generator(TONES) buffers fed
     straight to RX_buffer_demodulator(DIRECT).  TX is the unnormalised IFFT comb
