@@ -1,0 +1,85 @@
+"""Reduces gpurun_out/prof_<wl>/ (scratch/prof.sh) to the files committed under profiles/."""
+import collections, csv, glob, json, os, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "profiles")
+TAG = "r01"
+
+
+def newest(pattern):
+    fs = glob.glob(pattern, recursive=True)
+    return max(fs, key=os.path.getmtime) if fs else None
+
+
+def kernel_stats(src_dir, dst):
+    f = newest(os.path.join(src_dir, "trace", "**", "*kernel_stats.csv"))
+    if not f:
+        return None
+    rows = list(csv.reader(open(f)))
+    keep = [rows[0]] + [r for r in rows[1:] if r and r[0].startswith("gsdr::")]
+    with open(dst, "w", newline="") as o:
+        csv.writer(o, quoting=csv.QUOTE_ALL).writerows(keep)
+    return {r[0].split("(")[0]: float(r[3]) / 1e3 for r in keep[1:]}
+
+
+def overlap(src_dir):
+    """average number of gsdr:: kernels resident, and the steady-state period per main launch"""
+    f = newest(os.path.join(src_dir, "trace", "**", "*kernel_trace.csv"))
+    if not f:
+        return None
+    ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f))
+          if r["Kernel_Name"].startswith("gsdr::ddc") or r["Kernel_Name"].startswith("gsdr::absmax")]
+    main = sorted(e for e in ev if "ddc" in e[2])
+    main = main[len(main) // 3:]
+    if len(main) < 4:
+        return None
+    t0, t1 = main[0][0], main[-1][1]
+    busy = sum(min(e[1], t1) - max(e[0], t0) for e in ev if e[1] > t0 and e[0] < t1)
+    return dict(main_launches=len(main), period_us=round((main[-1][0] - main[0][0]) / (len(main) - 1) / 1e3, 2),
+                avg_kernels_resident=round(busy / (t1 - t0), 2))
+
+
+def pmc(src_dir, dst):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for d in sorted(glob.glob(os.path.join(src_dir, "pmc*"))):
+        if not os.path.isdir(d):
+            continue
+        f = newest(os.path.join(d, "**", "*counter_collection.csv"))
+        if not f:
+            continue
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0]
+            if k.startswith("gsdr::") and "source" not in k:
+                acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    out = {k: {c: round(sum(v) / len(v), 1) for c, v in d.items()} for k, d in acc.items()}
+    json.dump(out, open(dst, "w"), indent=1)
+    return out
+
+
+traffic = {}
+for wl, dom in (("c2", "ddc_mfma_ring_kernel"), ("c3", "ddc_mfma_ring_kernel"), ("pfb", "ddc_mfma_ring_kernel"),
+                ("c4", "chirp_lockin_kernel")):
+    src = os.path.join(ROOT, "gpurun_out", "prof_" + wl)
+    if not os.path.isdir(src):
+        continue
+    st = kernel_stats(src, os.path.join(OUT, f"{TAG}_{wl}_kernel_stats.csv"))
+    pm = pmc(src, os.path.join(OUT, f"{TAG}_{wl}_pmc.json"))
+    ov = overlap(src)
+    io = os.path.join(ROOT, "gpurun_out", "prof_" + wl + "_io")
+    st_io = kernel_stats(io, os.path.join(OUT, f"{TAG}_{wl}_inorder_kernel_stats.csv")) if os.path.isdir(io) else None
+    k = "gsdr::" + dom
+    c = pm.get(k, {})
+    entry = {"kernel": k, "rocprof_avg_us": round(st[k], 2) if st and k in st else None}
+    if st_io and k in st_io:
+        entry["rocprof_avg_us_inorder"] = round(st_io[k], 2)
+    if ov:
+        entry["timeline"] = ov
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        entry.update(FETCH_SIZE_KB_raw=c["FETCH_SIZE"], WRITE_SIZE_KB_raw=c["WRITE_SIZE"],
+                     hbm_bytes_per_launch=int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024),
+                     note="FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of streamed reads); "
+                          "counters are collected with the dispatches serialised (kernel alone on the chip); "
+                          "scalar-load and 8-B-per-lane store widths are uncalibrated, so treat as +-2x")
+    traffic[wl] = entry
+    print(wl, json.dumps(entry))
+json.dump(traffic, open(os.path.join(OUT, "traffic.json"), "w"), indent=1)
