@@ -183,7 +183,7 @@ def run_steps_pipelined(dem, bufs, outs, steps, k0=0):
         pending -= 1
 
 
-PIPE_DEPTH = 3
+PIPE_DEPTH = int(os.environ.get("GSDR_BENCH_DEPTH", "3"))   # buffers outstanding, <= GSDR_PIPELINE_DEPTH (4)
 
 
 def time_workload(wl, device, seed, steps, warmup, dist=None, n_tones=None, profile=True,

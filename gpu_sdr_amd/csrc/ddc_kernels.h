@@ -91,7 +91,7 @@ struct MfmaLaunch {
     const float2 *ptab;        // [ceil(nk8/KS)][NT32*32]  w_n^(hi*PK)
     const float2 *dtab;        // [32][NT32*32]            w_n^(row*M)
     const unsigned *fmod;      // [NT32*32]
-    const unsigned *maxbits;   // [3][16] absmax slots (16 partial maxima each)
+    const unsigned *maxbits;   // [slots][16] absmax slots (16 partial maxima each)
     float2 *out;
     float2 *carry_out;         // AsmRingDirect: receives x[nx - carry_len .. nx); `head` is the carry read
     MfmaShape sh;

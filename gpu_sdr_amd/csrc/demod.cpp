@@ -31,6 +31,11 @@ thread_local std::string g_create_error;
 
 constexpr int kMaxF = 8;           // tap phases the DDC kernel is instantiated for
 constexpr int kMaxEvents = 8192;   // profiling ring
+// Pipelined entries: compute streams that consecutive DIRECT calls go to in turn, and the
+// sets of staging buffers / scale slots that keeps the calls in flight apart (pipeline_compute)
+constexpr int kPipeStreams = 3;
+constexpr int kStageSets = kPipeStreams + 1;
+constexpr int kScaleSlots = kPipeStreams + 2;
 
 inline int env_int(const char *name, int dflt) {
     const char *v = std::getenv(name);
@@ -98,13 +103,14 @@ struct gsdr_demod {
     float *d_mtaps = nullptr;
     unsigned *d_mfmod = nullptr, *d_maxbits = nullptr;
     // [carry | first rows' samples | zeros] and [last rows' samples | zeros], see absmax_kernel.
-    // Three of each, used in turn: the staging pass of call j writes set j%3 (and the carry
-    // part of head (j+1)%3) while the main kernel of call j-1 may still read set (j-1)%3.
-    float2 *d_head[3] = {nullptr, nullptr, nullptr};
-    float2 *d_tail[3] = {nullptr, nullptr, nullptr};
+    // kStageSets of each, used in turn: the staging pass of call j writes set j (and the carry
+    // part of head j+1) while the main kernels of calls j-1 .. j-kPipeStreams+1 may still read theirs.
+    float2 *d_head[kStageSets] = {};
+    float2 *d_tail[kStageSets] = {};
     // pipelined entries (gsdr_demod_submit*): consecutive DIRECT calls go to two compute
     // streams in turn, so that their kernels overlap (see pipeline_compute)
-    hipStream_t s_main[2] = {nullptr, nullptr};
+    hipStream_t s_main[kPipeStreams] = {};
+    int pipe_streams = 2;              // how many of them are used (GSDR_PIPE_STREAMS)
     hipEvent_t ev_abs[4] = {nullptr, nullptr, nullptr, nullptr};    // staging pass of call j done
     bool pipe_overlap = false;         // set around the compute of an overlapped call
     unsigned long long call_no = 0;    // absmax slot rotation
@@ -385,8 +391,8 @@ int setup_mfma(gsdr_demod *h, bool direct, const std::vector<long long> &tone) {
     HIPCHK(h, upload(&h->d_dtab, dtab));
     HIPCHK(h, upload(&h->d_mtaps, taps));
     HIPCHK(h, upload(&h->d_mfmod, fmod));
-    HIPCHK(h, dev_alloc(&h->d_maxbits, 4 * 16));   // four slots of 16 partial maxima
-    HIPCHK(h, hipMemset(h->d_maxbits, 0, 4 * 16 * sizeof(unsigned)));
+    HIPCHK(h, dev_alloc(&h->d_maxbits, kScaleSlots * 16));   // slots of 16 partial maxima
+    HIPCHK(h, hipMemset(h->d_maxbits, 0, kScaleSlots * 16 * sizeof(unsigned)));
     gsdr::MfmaShape &sh = h->mf;
     sh.N = h->ddc_channels;
     sh.NT32 = pl.ntg * pl.TT;
@@ -409,7 +415,7 @@ int setup_mfma(gsdr_demod *h, bool direct, const std::vector<long long> &tone) {
         const size_t reach = (size_t)((pl.nk8 + pl.PK / 8 - 1) / (pl.PK / 8)) * pl.PK;   // whole phasor blocks
         const size_t head_n = (size_t)sh.carry_len + 32u * (size_t)M + reach + 8;
         const size_t tail_n = (size_t)(32 + F) * (size_t)M + reach + 8;
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < kStageSets; ++i) {
             HIPCHK(h, dev_alloc(&h->d_head[i], head_n));
             HIPCHK(h, hipMemset(h->d_head[i], 0, head_n * sizeof(float2)));
             HIPCHK(h, dev_alloc(&h->d_tail[i], tail_n));
@@ -529,11 +535,11 @@ int autotune_chunks(gsdr_demod *h, int nblk) {
 int enqueue_mfma(gsdr_demod *h, const float2 *in, float2 *raw, long long raw_new0, long long nx,
                  int nout, unsigned idx_base, float2 *out, hipStream_t st) {
     // slots: this buffer, the previous one, the one the staging pass clears for the next call.
-    // Four, so that the pass of call j+1 (clearing slot j+2) leaves alone what the main kernel
-    // of call j still reads (slots j and j-1) when the two overlap.
-    const int cur = (int)(h->call_no % 4), prev = (int)((h->call_no + 3) % 4),
-              next = (int)((h->call_no + 1) % 4);
-    const int hs = (int)(h->call_no % 3), hs_next = (int)((h->call_no + 1) % 3);
+    // kScaleSlots of them, so that the pass of call j (writing slot j, clearing slot j+1) leaves
+    // alone what the main kernels of the calls still in flight read (slots j-1 .. j-kPipeStreams).
+    const int cur = (int)(h->call_no % kScaleSlots), prev = (int)((h->call_no + kScaleSlots - 1) % kScaleSlots),
+              next = (int)((h->call_no + 1) % kScaleSlots);
+    const int hs = (int)(h->call_no % kStageSets), hs_next = (int)((h->call_no + 1) % kStageSets);
     gsdr::MfmaLaunch a{};
     a.sh = h->mf;
     a.sh.nout = nout;
@@ -1046,8 +1052,10 @@ static int pipeline_init(gsdr_demod *h) {
     // the reference gives its demodulator stream (cpp/USRP_demodulator.cpp:44).
     int prio_least = 0, prio_greatest = 0;
     HIPCHK(h, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < kPipeStreams; ++i)
         HIPCHK(h, hipStreamCreateWithPriority(&h->s_main[i], hipStreamNonBlocking, prio_least));
+    h->pipe_streams = env_int("GSDR_PIPE_STREAMS", 2);
+    if (h->pipe_streams < 1 || h->pipe_streams > kPipeStreams) h->pipe_streams = 2;
     for (int i = 0; i < 4; ++i) HIPCHK(h, hipEventCreateWithFlags(&h->ev_abs[i], hipEventDisableTiming));
     return 0;
 }
@@ -1055,21 +1063,23 @@ static int pipeline_init(gsdr_demod *h) {
 // The kernels of one pipelined buffer; records sl.done behind them.  `up`: event the input
 // becomes ready with (nullptr: it is ready).
 //
-// DIRECT on the staged matrix-core kernel: call j runs on compute stream j & 1, so the
-// kernels of consecutive buffers overlap and the next buffer fills the compute units that
-// the last workgroups of this one leave idle.  What call j needs from its neighbours:
+// DIRECT on the staged matrix-core kernel: call j runs on compute stream j % S (S =
+// GSDR_PIPE_STREAMS, 2 by default, at most kPipeStreams), so the kernels of consecutive buffers
+// overlap and the next buffer fills the compute units that the last workgroups of this one
+// leave idle.  What call j needs from its neighbours:
 //   - its staging pass follows the pass of call j-1 (which wrote the carry in front of this
 //     call's head copy and cleared this call's scale slot): one event, long complete when
 //     it is waited for;
-//   - everything it overwrites was last read by the main kernels of calls j-2 (same stream)
-//     and j-3 (in front of pass j-1 on the other stream); the main kernel of call j-1 reads
-//     head/tail set (j-1)%3 and slots j-1, j-2, the pass of call j writes head/tail set j%3,
-//     the carry part of head (j+1)%3, slot j and clears slot j+1 (mod 4): disjoint.
+//   - everything it overwrites was last read by main kernels that are finished: call j-S ran
+//     on the same stream, calls j-S-1 .. sit in front of pass j-1 on their streams.  The main
+//     kernels of calls j-1 .. j-S+1 may still run: they read head/tail sets j-1 .. j-S+1 and
+//     slots j-1 .. j-S, the pass of call j writes head/tail set j, the carry part of head j+1,
+//     slot j and clears slot j+1 -- disjoint modulo kStageSets = S+1 and kScaleSlots = S+2.
 // Every other mode keeps the one compute stream.  GSDR_PIPE_OVERLAP=0 does so for DIRECT too.
 static int pipeline_compute(gsdr_demod *h, gsdr_demod::Slot &sl, hipEvent_t up, const float2 *in, float2 *out) {
     const bool overlap = env_int("GSDR_PIPE_OVERLAP", 1) != 0 && h->mfma && h->mode == GSDR_DIRECT &&
                          h->decim > 0 && h->mf_kind != gsdr::MfmaKernel::AsmRingDirect;
-    hipStream_t cs = overlap ? h->s_main[h->call_no & 1] : h->stream;
+    hipStream_t cs = overlap ? h->s_main[h->call_no % (unsigned)h->pipe_streams] : h->stream;
     if (up) HIPCHK(h, hipStreamWaitEvent(cs, up, 0));
     if (overlap && h->call_no > 0) HIPCHK(h, hipStreamWaitEvent(cs, h->ev_abs[(h->call_no - 1) % 4], 0));
     h->pipe_overlap = overlap;
@@ -1150,7 +1160,7 @@ void gsdr_demod_close(gsdr_demod *h) {
     if (!h) return;
     if (h->device >= 0) (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < kPipeStreams; ++i)
         if (h->s_main[i]) (void)hipStreamSynchronize(h->s_main[i]);
     if (h->s_up) (void)hipStreamSynchronize(h->s_up);
     if (h->s_down) (void)hipStreamSynchronize(h->s_down);
@@ -1161,7 +1171,7 @@ void gsdr_demod_close(gsdr_demod *h) {
         if (sl.done) (void)hipEventDestroy(sl.done);
         if (sl.down) (void)hipEventDestroy(sl.down);
     }
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < kPipeStreams; ++i)
         if (h->s_main[i]) (void)hipStreamDestroy(h->s_main[i]);
     for (int i = 0; i < 4; ++i)
         if (h->ev_abs[i]) (void)hipEventDestroy(h->ev_abs[i]);
@@ -1175,10 +1185,13 @@ void gsdr_demod_close(gsdr_demod *h) {
                     h->d_wrem,    h->d_fmod,    h->d_tails,    h->d_carry[0], h->d_carry[1],
                     h->d_raw,     h->d_profile, h->d_ccarry[0], h->d_ccarry[1],
                     h->d_bfrag,   h->d_ptab,    h->d_dtab,     h->d_mtaps,    h->d_mfmod,
-                    h->d_maxbits, h->d_head[0], h->d_head[1], h->d_head[2],
-                    h->d_tail[0], h->d_tail[1], h->d_tail[2]};
+                    h->d_maxbits};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    for (int i = 0; i < kStageSets; ++i) {
+        if (h->d_head[i]) (void)hipFree(h->d_head[i]);
+        if (h->d_tail[i]) (void)hipFree(h->d_tail[i]);
+    }
     if (h->stream) (void)hipStreamDestroy(h->stream);  // ref: 03_implement.md:58-63
     delete h;
 }

@@ -672,8 +672,9 @@ def test_pipelined_submit_wait_equals_process(cuda_device, gsdr_lib):
         b.close()
 
 
-@pytest.mark.parametrize("overlap", ["1", "0"])
-def test_pipelined_submit_device_overlapping_buffers(cuda_device, gsdr_lib, oracle_mod, monkeypatch, overlap):
+@pytest.mark.parametrize("overlap,streams", [("1", "2"), ("1", "3"), ("0", "2")])
+def test_pipelined_submit_device_overlapping_buffers(cuda_device, gsdr_lib, oracle_mod, monkeypatch, overlap,
+                                                     streams):
     """gsdr_demod_submit_device: the main kernels of consecutive DIRECT buffers run on two
     streams and overlap (the staging passes stay in order).  Buffers of very different
     loudness follow each other, so a kernel that picked up its neighbour's scale slot, head
@@ -683,6 +684,7 @@ def test_pipelined_submit_device_overlapping_buffers(cuda_device, gsdr_lib, orac
     monkeypatch.setenv("GSDR_DDC_MFMA", "1")
     monkeypatch.setenv("GSDR_MFMA_ASM", "2")
     monkeypatch.setenv("GSDR_PIPE_OVERLAP", overlap)
+    monkeypatch.setenv("GSDR_PIPE_STREAMS", streams)
     N, rate, M, F, L = 256, 10_000_000, 100, 4, 200_000
     rng = np.random.default_rng(314)
     freq = rng.choice(np.arange(-rate // 2 + 1, rate // 2), size=N, replace=False)
@@ -701,7 +703,7 @@ def test_pipelined_submit_device_overlapping_buffers(cuda_device, gsdr_lib, orac
     torch.cuda.synchronize()
     got, pending = [], []
     for k, x in enumerate(xs):
-        if len(pending) == 3:
+        if len(pending) == 4:
             j = pending.pop(0)
             got.append(outs[j][:b.wait()].cpu().numpy())
         b.submit_device(x, outs[k])
