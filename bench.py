@@ -367,7 +367,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--api", default="auto", choices=["auto", "inorder", "pipelined"],
-                    help="entry the timed steps go through; auto = pipelined for the DDC (DIRECT) workloads")
+                    help="entry the timed steps go through; auto = pipelined for the DDC (DIRECT, TONES) workloads")
     ap.add_argument("--no-extras", action="store_true", help="skip c3/c4/max-tone extras")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     args = ap.parse_args()
@@ -396,7 +396,7 @@ def main():
 
     wl = WORKLOADS[args.workload]
     seed = stream_seed(rank)
-    api = args.api if args.api != "auto" else ("pipelined" if wl["kind"] == "direct" else "inorder")
+    api = args.api if args.api != "auto" else ("pipelined" if wl["kind"] in ("direct", "pfb") else "inorder")
     r = time_workload(wl, device, seed, args.steps, args.warmup, dist, ctl_device=ctl_device, api=api)
     samples_total = args.steps * L * world
     value = samples_total / r["elapsed"] / 1e6

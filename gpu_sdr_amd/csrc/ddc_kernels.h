@@ -109,7 +109,8 @@ void mfma_build_tables(const MfmaPlan &pl, const std::vector<unsigned> &fmod_in,
                        std::vector<unsigned> &fmod, float &unscale);
 hipError_t launch_absmax(const float2 *x, long long n, unsigned *slots, int cur, int next,
                          float2 *head_cur, long long head_n, float2 *head_next, int carry_len,
-                         float2 *tail, long long tail0, hipStream_t st);
+                         float2 *tail, long long tail0, hipStream_t st, const float2 *extra_src = nullptr,
+                         float2 *extra_dst = nullptr, long long extra_n = 0);
 // AsmRing: assembly main loop, operand shared through an LDS ring (production);
 // AsmSolo: assembly main loop, every wave converts its own operand; Cxx: compiler-scheduled
 // (TT, PK, W apply to it only; the assembly kernels are TT = 1, PK = 32, W = 4).

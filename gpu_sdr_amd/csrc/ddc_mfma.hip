@@ -622,11 +622,28 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
 //   * head_cur[carry_len + i] = x[i] for i < head_n (row tile 0 reads [carry | x) there);
 //   * head_next[i - (n - carry_len)] = x[i] for the last carry_len samples (next call's carry);
 //   * tail[i - tail0] = x[i] for i >= tail0 (the last row tile reads there; zeros follow).
-// All destinations may be null.
+// All destinations may be null.  Workgroups from `main_blocks` on copy extra_src[0..extra_n)
+// to extra_dst (TONES: the unconsumed end of the previous raw window to the front of this
+// one; its maximum is in the previous call's slot already).
 __global__ __launch_bounds__(256) void absmax_kernel(const float2 *x, long long n, long long chunk,
                                                      unsigned *slots, int cur, int next, float2 *head_cur,
                                                      long long head_n, float2 *head_next, int carry_len,
-                                                     float2 *tail, long long tail0) {
+                                                     float2 *tail, long long tail0, unsigned main_blocks,
+                                                     const float2 *extra_src, float2 *extra_dst,
+                                                     long long extra_n) {
+    if (blockIdx.x >= main_blocks) {
+        const long long e0 = (long long)(blockIdx.x - main_blocks) * chunk;
+        const long long e1 = e0 + chunk < extra_n ? e0 + chunk : extra_n;
+        for (long long base = e0 + threadIdx.x; base < e1; base += 1024) {
+            float2 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = base + 256 * k < e1 ? extra_src[base + 256 * k] : make_float2(0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (base + 256 * k < e1) extra_dst[base + 256 * k] = v[k];
+        }
+        return;
+    }
     // one contiguous chunk of samples per workgroup (chunk is even)
     const long long c0 = (long long)blockIdx.x * chunk;
     const long long c1 = c0 + chunk < n ? c0 + chunk : n;
@@ -815,8 +832,10 @@ void mfma_build_tables(const MfmaPlan &pl, const std::vector<unsigned> &fmod_in,
 
 hipError_t launch_absmax(const float2 *x, long long n, unsigned *slots, int cur, int next,
                          float2 *head_cur, long long head_n, float2 *head_next, int carry_len,
-                         float2 *tail, long long tail0, hipStream_t st) {
-    if (n < 1 || carry_len < 0 || carry_len > n || head_n < 0 || head_n > n || tail0 < 0 || tail0 > n)
+                         float2 *tail, long long tail0, hipStream_t st, const float2 *extra_src,
+                         float2 *extra_dst, long long extra_n) {
+    if (n < 1 || carry_len < 0 || carry_len > n || head_n < 0 || head_n > n || tail0 < 0 || tail0 > n ||
+        extra_n < 0 || (extra_n > 0 && (!extra_src || !extra_dst)))
         return hipErrorInvalidValue;
     // samples per workgroup (GSDR_ABSMAX_CHUNK, default 4096), at most 1024 workgroups, even chunks
     static const long long want = [] {
@@ -830,8 +849,10 @@ hipError_t launch_absmax(const float2 *x, long long n, unsigned *slots, int cur,
     long long chunk = (n + blocks - 1) / blocks;
     chunk += chunk & 1;
     blocks = (n + chunk - 1) / chunk;
-    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n, chunk, slots, cur, next,
-                       head_cur, head_n, head_next, carry_len, tail, tail0);
+    const long long extra_blocks = (extra_n + chunk - 1) / chunk;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks + extra_blocks)), dim3(256), 0, st, x, n, chunk, slots,
+                       cur, next, head_cur, head_n, head_next, carry_len, tail, tail0, (unsigned)blocks, extra_src,
+                       extra_dst, extra_n);
     return hipGetLastError();
 }
 

@@ -113,12 +113,18 @@ struct gsdr_demod {
     int pipe_streams = 2;              // how many of them are used (GSDR_PIPE_STREAMS)
     hipEvent_t ev_abs[4] = {nullptr, nullptr, nullptr, nullptr};    // staging pass of call j done
     bool pipe_overlap = false;         // set around the compute of an overlapped call
+    unsigned long long pipe_seq = 0;   // overlapped calls so far
     unsigned long long call_no = 0;    // absmax slot rotation
     // ---- TONES ----
     std::vector<int> bins;
     int nfft = 0, batching = 0;
     gsdr_buffer_helper bh{};
-    float2 *d_raw = nullptr;           // raw_input (ref :143)
+    // raw_input (ref :143): kStageSets windows used in turn.  The staging of call j copies the
+    // unconsumed end of window j-1 to the front of window j and appends the new buffer, so the
+    // kernels of call j-1 may still read their window (the reference moves it in place, :504-509).
+    float2 *d_win[kStageSets] = {};
+    unsigned long long win_seq = 0;    // TONES/NOISE calls so far
+    long long prev_spare_begin = 0, prev_spare_samples = 0;
     // ---- CHIRP ----
     ChirpShape cs{};
     int ppt = 0;
@@ -431,7 +437,8 @@ int setup_mfma(gsdr_demod *h, bool direct, const std::vector<long long> &tone) {
 // the rows read `in` (and its head/tail copies).  TONES: the pass also appends
 // `in` to the raw window at raw_new0 and the rows read raw[0 .. nx).
 int enqueue_mfma(gsdr_demod *h, const float2 *in, float2 *raw, long long raw_new0, long long nx,
-                 int nout, unsigned idx_base, float2 *out, hipStream_t st);
+                 int nout, unsigned idx_base, float2 *out, hipStream_t st, const float2 *spare_src = nullptr,
+                 long long spare_n = 0);
 
 int record_begin(gsdr_demod *h, hipStream_t st, hipEvent_t *stop) {
     *stop = nullptr;
@@ -533,7 +540,8 @@ int autotune_chunks(gsdr_demod *h, int nblk) {
 }
 
 int enqueue_mfma(gsdr_demod *h, const float2 *in, float2 *raw, long long raw_new0, long long nx,
-                 int nout, unsigned idx_base, float2 *out, hipStream_t st) {
+                 int nout, unsigned idx_base, float2 *out, hipStream_t st, const float2 *spare_src,
+                 long long spare_n) {
     // slots: this buffer, the previous one, the one the staging pass clears for the next call.
     // kScaleSlots of them, so that the pass of call j (writing slot j, clearing slot j+1) leaves
     // alone what the main kernels of the calls still in flight read (slots j-1 .. j-kPipeStreams).
@@ -549,10 +557,12 @@ int enqueue_mfma(gsdr_demod *h, const float2 *in, float2 *raw, long long raw_new
     a.sh.slot_cur = cur;
     a.sh.slot_prev = prev;
     if (raw) {
-        // TONES: one pass appends the buffer to the raw window and takes its maximum;
-        // every row reads the window itself (allocated twice as long as it gets)
+        // TONES: one pass brings the carried samples to the front of this call's raw window,
+        // appends the buffer and takes its maximum; every row reads the window itself
+        // (allocated twice as long as it gets)
         HIPCHK(h, gsdr::launch_absmax(in, h->L, h->d_maxbits, cur, next, raw + raw_new0, h->L, nullptr, 0,
-                                      nullptr, h->L, st));
+                                      nullptr, h->L, st, spare_src, raw, spare_n));
+        if (h->pipe_overlap) HIPCHK(h, hipEventRecord(h->ev_abs[h->pipe_seq % 4], st));
         a.x = a.head = a.tail = raw;
         a.sh.tail0 = 0;
     } else if (h->mf_kind == gsdr::MfmaKernel::AsmRingDirect) {
@@ -569,7 +579,7 @@ int enqueue_mfma(gsdr_demod *h, const float2 *in, float2 *raw, long long raw_new
         if (head_n > h->L) head_n = h->L;
         HIPCHK(h, gsdr::launch_absmax(in, h->L, h->d_maxbits, cur, next, h->d_head[hs], head_n,
                                       h->d_head[hs_next], cl, h->d_tail[hs], t0, st));
-        if (h->pipe_overlap) HIPCHK(h, hipEventRecord(h->ev_abs[h->call_no % 4], st));
+        if (h->pipe_overlap) HIPCHK(h, hipEventRecord(h->ev_abs[h->pipe_seq % 4], st));
         a.x = in;
         a.head = h->d_head[hs];
         a.tail = h->d_tail[hs];
@@ -662,15 +672,26 @@ int enqueue_direct(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t st)
 int enqueue_pfb(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t st) {
     // :491-495  new buffer goes after the carried samples
     const int cb = h->bh.current_batch;
-    if (!(cb > 0 && h->mfma))
-        HIPCHK(h, hipMemcpyAsync(h->d_raw + h->bh.new_0, in, (size_t)h->L * sizeof(float2),
+    float2 *win = h->d_win[h->win_seq % kStageSets];
+    const float2 *spare = h->prev_spare_samples > 0
+                              ? h->d_win[(h->win_seq + kStageSets - 1) % kStageSets] + h->prev_spare_begin
+                              : nullptr;
+    if (!(cb > 0 && h->mfma)) {
+        // :504-509 of the previous call (carry the unconsumed samples to the front), then :491-495
+        if (spare)
+            HIPCHK(h, hipMemcpyAsync(win, spare, (size_t)h->prev_spare_samples * sizeof(float2),
+                                     hipMemcpyDeviceToDevice, st));
+        HIPCHK(h, hipMemcpyAsync(win + h->bh.new_0, in, (size_t)h->L * sizeof(float2),
                                  hipMemcpyDeviceToDevice, st));
+        if (h->pipe_overlap) HIPCHK(h, hipEventRecord(h->ev_abs[h->pipe_seq % 4], st));
+    }
     if (cb > 0 && h->mfma) {
-        if (enqueue_mfma(h, in, h->d_raw, h->bh.new_0, (long long)(cb + h->F - 1) * h->M, cb, 0u, out, st))
+        if (enqueue_mfma(h, in, win, h->bh.new_0, (long long)(cb + h->F - 1) * h->M, cb, 0u, out, st, spare,
+                         h->prev_spare_samples))
             return -1;
     } else if (cb > 0) {
         DdcLaunch a{};
-        a.x = h->d_raw;
+        a.x = win;
         a.taps_t = h->d_taps_t;
         a.taps_p = h->d_taps_p;
         a.btab = h->d_btab;
@@ -692,7 +713,7 @@ int enqueue_pfb(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t st) {
         a.pipe = h->pipe;
         a.lds_bytes = h->lds_bytes;
         a.sh.prefetch = h->prefetch;
-        a.sh.xlast = (long long)a.sh.nblk * h->M + h->pad - 4;  // d_raw is twice the window
+        a.sh.xlast = (long long)a.sh.nblk * h->M + h->pad - 4;  // a window is allocated twice as long
         a.sh.g_off = h->F - 1;      // DDC output G <-> frame r = G-(F-1)
         const int nch = pick_chunks(h, a.sh.nblk);
         a.sh.nch = nch;
@@ -701,16 +722,10 @@ int enqueue_pfb(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t st) {
         if (record_begin(h, st, &stop)) return -1;
         HIPCHK(h, gsdr::launch_ddc(h->F, h->K, a, st, stop));
     }
-    // :504-509 carry the unconsumed samples to the front (ranges may overlap,
-    // so go through the spare half of the raw buffer)
-    if (h->bh.spare_samples > 0 && h->bh.spare_begin > 0) {
-        float2 *tmp = h->d_raw + (size_t)h->nfft * h->batching;
-        HIPCHK(h, hipMemcpyAsync(tmp, h->d_raw + h->bh.spare_begin,
-                                 (size_t)h->bh.spare_samples * sizeof(float2),
-                                 hipMemcpyDeviceToDevice, st));
-        HIPCHK(h, hipMemcpyAsync(h->d_raw, tmp, (size_t)h->bh.spare_samples * sizeof(float2),
-                                 hipMemcpyDeviceToDevice, st));
-    }
+    // :504-509 the unconsumed samples go to the front of the next call's window (see above)
+    h->prev_spare_begin = h->bh.spare_begin;
+    h->prev_spare_samples = h->bh.spare_samples > 0 ? h->bh.spare_samples : 0;
+    h->win_seq++;
     const int ret = h->ddc_channels * cb;  // :546 (TONES), copy_size :638 (NOISE)
     gsdr_buffer_helper_update(&h->bh);   // :552
     return ret;
@@ -914,13 +929,14 @@ gsdr_demod *gsdr_demod_create(const gsdr_param_c *p) {
                                   (int)(h->L / h->nfft) + F + 6);
             h->kernel_name = h->pipe ? gsdr::ddc_flat_kernel_name() : gsdr::ddc_kernel_name();
             if (!rc) {
-                // raw_input (:143) plus an equally long scratch half for the carry move
+                // raw_input (:143) plus an equally long half of padding behind it, kStageSets times
                 const size_t n = (size_t)h->nfft * h->batching * 2;
-                if (dev_alloc(&h->d_raw, n) != hipSuccess ||
-                    hipMemset(h->d_raw, 0, n * sizeof(float2)) != hipSuccess) {
-                    h->err = "raw_input allocation failed";
-                    rc = -1;
-                }
+                for (int i = 0; i < kStageSets && !rc; ++i)
+                    if (dev_alloc(&h->d_win[i], n) != hipSuccess ||
+                        hipMemset(h->d_win[i], 0, n * sizeof(float2)) != hipSuccess) {
+                        h->err = "raw_input allocation failed";
+                        rc = -1;
+                    }
             }
             // every carried sample of the raw window must come from the previous buffer
             // (absmax covers this buffer and the one before)
@@ -1077,15 +1093,17 @@ static int pipeline_init(gsdr_demod *h) {
 //     slot j and clears slot j+1 -- disjoint modulo kStageSets = S+1 and kScaleSlots = S+2.
 // Every other mode keeps the one compute stream.  GSDR_PIPE_OVERLAP=0 does so for DIRECT too.
 static int pipeline_compute(gsdr_demod *h, gsdr_demod::Slot &sl, hipEvent_t up, const float2 *in, float2 *out) {
-    const bool overlap = env_int("GSDR_PIPE_OVERLAP", 1) != 0 && h->mfma && h->mode == GSDR_DIRECT &&
-                         h->decim > 0 && h->mf_kind != gsdr::MfmaKernel::AsmRingDirect;
-    hipStream_t cs = overlap ? h->s_main[h->call_no % (unsigned)h->pipe_streams] : h->stream;
+    const bool ddc = (h->mode == GSDR_DIRECT && h->decim > 0 && h->mf_kind != gsdr::MfmaKernel::AsmRingDirect) ||
+                     h->mode == GSDR_TONES || h->mode == GSDR_NOISE;
+    const bool overlap = env_int("GSDR_PIPE_OVERLAP", 1) != 0 && h->mfma && ddc;
+    hipStream_t cs = overlap ? h->s_main[h->pipe_seq % (unsigned)h->pipe_streams] : h->stream;
     if (up) HIPCHK(h, hipStreamWaitEvent(cs, up, 0));
-    if (overlap && h->call_no > 0) HIPCHK(h, hipStreamWaitEvent(cs, h->ev_abs[(h->call_no - 1) % 4], 0));
+    if (overlap && h->pipe_seq > 0) HIPCHK(h, hipStreamWaitEvent(cs, h->ev_abs[(h->pipe_seq - 1) % 4], 0));
     h->pipe_overlap = overlap;
     const int n = gsdr_demod_process_device(h, reinterpret_cast<const gsdr_c64 *>(in),
                                             reinterpret_cast<gsdr_c64 *>(out), cs);
     h->pipe_overlap = false;
+    if (overlap) h->pipe_seq++;
     if (n < 0) return -1;
     HIPCHK(h, hipEventRecord(sl.done, cs));
     return n;
@@ -1183,12 +1201,13 @@ void gsdr_demod_close(gsdr_demod *h) {
     }
     void *ptrs[] = {h->d_in,      h->d_out,     h->d_taps_t,   h->d_taps_p,   h->d_stage,    h->d_btab,     h->d_wk,
                     h->d_wrem,    h->d_fmod,    h->d_tails,    h->d_carry[0], h->d_carry[1],
-                    h->d_raw,     h->d_profile, h->d_ccarry[0], h->d_ccarry[1],
+                    h->d_profile, h->d_ccarry[0], h->d_ccarry[1],
                     h->d_bfrag,   h->d_ptab,    h->d_dtab,     h->d_mtaps,    h->d_mfmod,
                     h->d_maxbits};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (int i = 0; i < kStageSets; ++i) {
+        if (h->d_win[i]) (void)hipFree(h->d_win[i]);
         if (h->d_head[i]) (void)hipFree(h->d_head[i]);
         if (h->d_tail[i]) (void)hipFree(h->d_tail[i]);
     }

@@ -727,6 +727,56 @@ def test_pipelined_submit_device_overlapping_buffers(cuda_device, gsdr_lib, orac
     b.close()
 
 
+@pytest.mark.parametrize("streams", ["2", "3"])
+def test_pipelined_submit_device_tones(cuda_device, gsdr_lib, oracle_mod, monkeypatch, streams):
+    """TONES through gsdr_demod_submit_device: the raw windows of consecutive buffers are
+    separate (the staging pass of a call copies the unconsumed end of the previous window),
+    so their kernels overlap too.  L is no multiple of nfft: the carried length changes from
+    buffer to buffer.  Bit-equal to the in-order entry, within tolerance of the oracle."""
+    import torch
+    monkeypatch.setenv("GSDR_DDC_MFMA", "1")
+    monkeypatch.setenv("GSDR_PIPE_STREAMS", streams)
+    rate, nfft, F, L, N = 10_000_000, 250, 4, 100_003, 96
+    rng = np.random.default_rng(2718)
+    freq = rng.choice(np.arange(-rate // 2 + 1, rate // 2), size=N, replace=False)
+    a, b = make_pfb(freq, rate, nfft, F, L), make_pfb(freq, rate, nfft, F, L)
+    assert b.kernel_name.startswith("ddc_mfma")
+    ref = oracle_mod.Pfb(freq, rate, nfft, F, L)
+    scales = [1.0, 1e-3, 50.0, 1.0, 1e-2, 1.0, 7.0, 1.0, 1.0]
+    xs = [torch.from_numpy((crandn(rng, L) * np.float32(sc)).astype(np.complex64)).to(cuda_device) for sc in scales]
+    out_a = torch.empty(a.out_capacity, dtype=torch.complex64, device=cuda_device)
+    want = []
+    for x in xs:
+        n = a.process_device(x, out_a)
+        torch.cuda.synchronize()
+        want.append(out_a[:n].cpu().numpy())
+    outs = [torch.zeros(b.out_capacity, dtype=torch.complex64, device=cuda_device) for _ in xs]
+    torch.cuda.synchronize()
+    got, pending = [], []
+    for k, x in enumerate(xs):
+        if len(pending) == 4:
+            j = pending.pop(0)
+            got.append(outs[j][:b.wait()].cpu().numpy())
+        b.submit_device(x, outs[k])
+        pending.append(k)
+    while pending:
+        j = pending.pop(0)
+        got.append(outs[j][:b.wait()].cpu().numpy())
+    assert [len(y) for y in got] == [len(y) for y in want]
+    assert len({len(y) for y in got}) > 1          # the batch count does change
+    for k, (y, yr) in enumerate(zip(got, want)):
+        np.testing.assert_array_equal(y, yr, err_msg="buffer %d" % k)
+    for k, x in enumerate(xs[:4]):
+        yo = ref.process(x.cpu().numpy())
+        assert yo.size == got[k].size
+        yo = yo.reshape(-1, N)
+        den = np.linalg.norm(yo, axis=0)
+        err = np.linalg.norm(got[k].reshape(-1, N) - yo, axis=0) / den
+        assert err.max() <= TOL, (k, err.max())
+    a.close()
+    b.close()
+
+
 def test_profile_sampling(cuda_device, gsdr_lib):
     """gsdr_demod_profile_enable(n): hipEvents around every n-th launch of the dominant kernel."""
     import torch
