@@ -646,16 +646,19 @@ def test_pipelined_submit_wait_equals_process(cuda_device, gsdr_lib):
     makers = [lambda: make_direct([1000, -2500, 77777], 1_000_000, 100, 4, 20_000),
               lambda: make_pfb([0, 125_000, -250_000], 1_000_000, 64, 4, 20_001),
               lambda: make_chirp(1_000_000, -100_000, 100_000, 50, 0.00035, 2, 5000),
+              lambda: g.RX_buffer_demodulator(g.param(mode="RX", rate=1_000_000, buffer_len=50_123, decim=0,
+                                                      pf_average=4, fft_tones=100, freq=[0],
+                                                      wave_type=[g.w_type.NOISE]), device_index=0),
               lambda: g.RX_buffer_demodulator(g.param(rate=1000, buffer_len=3000, wave_type=[]), device_index=0)]
     for mk in makers:
         a, b = mk(), mk()
         L = a.parameters.buffer_len
-        xs = [torch.from_numpy(crandn(rng, L)).pin_memory().numpy() for _ in range(7)]
-        outs = [torch.empty(a.out_capacity, dtype=torch.complex64).pin_memory().numpy() for _ in range(7)]
+        xs = [torch.from_numpy(crandn(rng, L)).pin_memory().numpy() for _ in range(9)]
+        outs = [torch.empty(a.out_capacity, dtype=torch.complex64).pin_memory().numpy() for _ in range(9)]
         want = [run_host(a, x) for x in xs]
         got, pending = [], []
         for k, x in enumerate(xs):
-            if len(pending) == 3:
+            if len(pending) == 4:
                 j = pending.pop(0)
                 got.append(outs[j][:b.wait()].copy())
             b.submit(x, outs[k])
