@@ -82,6 +82,22 @@ __device__ __forceinline__ Frag make_frag(const float4v xa, const float4v xb, co
 
 }  // namespace
 
+// Bit casts, workgroup barrier and lane exchange for the kernels compiled with
+// target("no-packed-fp32-ops"): the HIP header versions (__uint_as_float, __syncthreads,
+// __shfl_xor) are not always_inline, cannot be inlined into a function with other target
+// features, and end up as real calls (s_swappc_b64) there.
+__device__ __forceinline__ float bits_to_float(unsigned u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ unsigned float_to_bits(float f) { return __builtin_bit_cast(unsigned, f); }
+__device__ __forceinline__ void workgroup_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ unsigned lane_xor(unsigned v, int d) {
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    return (unsigned)__builtin_amdgcn_ds_bpermute((lane ^ d) << 2, (int)v);
+}
+
 // max |component| over this and the previous buffer: absmax_kernel keeps 16 partial
 // maxima per slot (float bits of non-negative numbers order like unsigned integers)
 __device__ __forceinline__ unsigned slot_max(const unsigned *slots, int cur, int prev) {
@@ -95,14 +111,14 @@ __device__ __forceinline__ unsigned slot_max(const unsigned *slots, int cur, int
     return m;
 }
 
-// w_n^(idx_base + 32*gt*M): the phasor of tone n at the first row of row tile gt
-// (float pair; independent of the loop's results, so the assembly kernels take it
-// before their main loop, where it hides behind the first loads)
-__device__ __forceinline__ float2 tile_phasor(const MfmaLaunch &a, int gt, int n) {
+// w_n^(idx_base + 32*gt*M): the phasor of tone n (fm = f_n mod rate) at the first row of
+// row tile gt.  The assembly kernels load fm before their main loop (the load then costs
+// nothing) and do the arithmetic behind it, in the shadow of the dtab loads.
+__device__ __forceinline__ float2 tile_phasor(const MfmaLaunch &a, int gt, unsigned fm) {
     const MfmaShape &sh = a.sh;
     const unsigned long long s_tile = mod_rate(
         (unsigned long long)sh.idx_base + (unsigned long long)(gt * 32) * sh.m_mod_rate, sh.rate, sh.rate_magic);
-    const unsigned long long ph = mod_rate((unsigned long long)a.fmod[n] * s_tile, sh.rate, sh.rate_magic);
+    const unsigned long long ph = mod_rate((unsigned long long)fm * s_tile, sh.rate, sh.rate_magic);
     double bre, bim;
     exact_phasor(ph, sh.inv_rate, bre, bim);
     return make_float2((float)bre, (float)bim);
@@ -133,7 +149,7 @@ __device__ __forceinline__ void store_rows(const MfmaLaunch &a, int gt, int n0, 
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) {
         const int n = n0 + tt * 32;
-        store_tile(a, gt, n, hh, invS, tile_phasor(a, gt, n), accr[tt], acci[tt]);
+        store_tile(a, gt, n, hh, invS, tile_phasor(a, gt, a.fmod[n]), accr[tt], acci[tt]);
     }
 }
 
@@ -203,8 +219,8 @@ __global__ __launch_bounds__(64 * W, TT == 1 ? 2 : 1) void ddc_mfma_kernel(const
     const unsigned mb = slot_max(a.maxbits, sh.slot_cur, sh.slot_prev);
     int se = 140 - (int)((mb >> 23) & 0xffu);       // |x| < 2^(e-126), |h'| <= 1  =>  |b| < 2^14
     se = se > 100 ? 100 : (se < -100 ? -100 : se);
-    const float S = __uint_as_float((unsigned)(127 + se) << 23);
-    const float invS = __uint_as_float((unsigned)(127 - se) << 23) * sh.unscale;
+    const float S = bits_to_float((unsigned)(127 + se) << 23);
+    const float invS = bits_to_float((unsigned)(127 - se) << 23) * sh.unscale;
 
     // ---- this lane's row of the A operand ----
     const int o = gt * 32 + r;
@@ -328,8 +344,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
     const unsigned mb = slot_max(a.maxbits, sh.slot_cur, sh.slot_prev);
     int se = 140 - (int)((mb >> 23) & 0xffu);
     se = se > 100 ? 100 : (se < -100 ? -100 : se);
-    const float S = __uint_as_float((unsigned)(127 + se) << 23);
-    const float invS = __uint_as_float((unsigned)(127 - se) << 23) * sh.unscale;
+    const float S = bits_to_float((unsigned)(127 + se) << 23);
+    const float invS = bits_to_float((unsigned)(127 - se) << 23) * sh.unscale;
 
     // scaled taps with zeros behind them: the loop's look-ahead reads up to three
     // k-steps past the window
@@ -350,7 +366,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
             if (i < nfill) *reinterpret_cast<float4v *>(table + i) = t4[k] * S;
         }
     }
-    __syncthreads();
+    workgroup_sync();
 
     // scalar bases + per-lane non-negative byte offsets (global_load ..., voffset, s[base])
     const int o = gt * 32 + r;
@@ -428,8 +444,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
     const unsigned mb = slot_max(a.maxbits, sh.slot_cur, sh.slot_prev);
     int se = 140 - (int)((mb >> 23) & 0xffu);
     se = se > 100 ? 100 : (se < -100 ? -100 : se);
-    const float S = __uint_as_float((unsigned)(127 + se) << 23);
-    const float invS = __uint_as_float((unsigned)(127 - se) << 23) * sh.unscale;
+    const float S = bits_to_float((unsigned)(127 + se) << 23);
+    const float invS = bits_to_float((unsigned)(127 - se) << 23) * sh.unscale;
 
     const int o = gt * 32 + r;
     const int oc = o < sh.nout ? o : sh.nout - 1;
@@ -459,7 +475,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
     const unsigned long long xb = (unsigned long long)xbase, tpb = (unsigned long long)a.taps,
                              ppb = (unsigned long long)a.ptab, bfb = (unsigned long long)a.bfrag;
     const int nhi = (sh.timing_mode & 2) ? 1 : (sh.nk8 + KS - 1) / KS;
-    const float2 base = tile_phasor(a, gt, n0);
+    const unsigned fm = a.fmod[n0];
     asm volatile(GSDR_MFMA_RING_TEXT
                  :
                  : [xo] "v"(xo), [to] "v"(to), [po] "v"(po), [bo] "v"(bo), [lane16] "v"(lane16), [wr16] "v"(wr16),
@@ -474,8 +490,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
                    [pstride] "s"(__builtin_amdgcn_readfirstlane((int)((unsigned)Np * 8u))),
                    [nhi] "s"(__builtin_amdgcn_readfirstlane(nhi)),
                    [scale] "v"(S),
-                   // not read by the loop: operands only so that the phasor is finished before it
-                   [bx] "v"(base.x), [by] "v"(base.y)
+                   // not read by the loop: an operand only so that the load is issued in front of it
+                   [fm] "v"(fm)
                  : GSDR_MFMA_RING_CLOBBERS);
     if (!active || (sh.timing_mode & 1)) return;
     float16v accr[1], acci[1];
@@ -489,7 +505,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
             acci[0][qd * 4 + j] = vi[j];
         }
     }
-    store_tile(a, gt, n0, hh, invS, base, accr[0], acci[0]);
+    store_tile(a, gt, n0, hh, invS, tile_phasor(a, gt, fm), accr[0], acci[0]);
 }
 
 // The ring kernel without its staging pass: ONE launch per buffer.  The loop reads the
@@ -545,25 +561,25 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
         for (int u = 0; u < 8; ++u)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const unsigned b = __float_as_uint(v[u][j]) & 0x7fffffffu;
+                const unsigned b = float_to_bits(v[u][j]) & 0x7fffffffu;
                 m = m > b ? m : b;
             }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
-        const unsigned t = (unsigned)__shfl_xor((int)m, d, 64);
+        const unsigned t = lane_xor(m, d);
         m = m > t ? m : t;
     }
     if (lane == 0) wmax[wave] = m;
-    __syncthreads();
+    workgroup_sync();
     unsigned mb = wmax[0];
 #pragma unroll
     for (int i = 1; i < W; ++i) mb = mb > wmax[i] ? mb : wmax[i];
     mb = (unsigned)__builtin_amdgcn_readfirstlane((int)mb);
     int se = 140 - (int)((mb >> 23) & 0xffu);
     se = se > 100 ? 100 : (se < -100 ? -100 : se);
-    const float S = __uint_as_float((unsigned)(127 + se) << 23);
-    const float invS = __uint_as_float((unsigned)(127 - se) << 23) * sh.unscale;
+    const float S = bits_to_float((unsigned)(127 + se) << 23);
+    const float invS = bits_to_float((unsigned)(127 - se) << 23) * sh.unscale;
 
     const int o = gt * 32 + r;
     const int oc = o < sh.nout ? o : sh.nout - 1;
@@ -581,7 +597,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
     const unsigned long long xb = (unsigned long long)a.x, cb = (unsigned long long)a.head,
                              tpb = (unsigned long long)a.taps, ppb = (unsigned long long)a.ptab,
                              bfb = (unsigned long long)a.bfrag;
-    const float2 base = tile_phasor(a, gt, n0);
+    const unsigned fm = a.fmod[n0];
     asm volatile(GSDR_MFMA_RINGD_TEXT
                  :
                  : [s0] "v"(s0), [to] "v"(to), [po] "v"(po), [bo] "v"(bo), [lane16] "v"(lane16), [wr16] "v"(wr16),
@@ -600,7 +616,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
                    [pstride] "s"(__builtin_amdgcn_readfirstlane((int)((unsigned)Np * 8u))),
                    [nhi] "s"(__builtin_amdgcn_readfirstlane(nhi)),
                    [scale] "v"(S),
-                   [bx] "v"(base.x), [by] "v"(base.y)
+                   [fm] "v"(fm)
                  : GSDR_MFMA_RINGD_CLOBBERS);
     if (!active || (sh.timing_mode & 1)) return;
     float16v accr[1], acci[1];
@@ -614,7 +630,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
             acci[0][qd * 4 + j] = vi[j];
         }
     }
-    store_tile(a, gt, n0, hh, invS, base, accr[0], acci[0]);
+    store_tile(a, gt, n0, hh, invS, tile_phasor(a, gt, fm), accr[0], acci[0]);
 }
 
 // One pass over the new buffer x[0..n):

@@ -780,6 +780,47 @@ def test_pipelined_submit_device_tones(cuda_device, gsdr_lib, oracle_mod, monkey
     b.close()
 
 
+def test_pipelined_soak_full_size(cuda_device, gsdr_lib, monkeypatch):
+    """400 buffers of the C2 shape (256 tones, decim 100, 1 M samples) through the overlapped
+    entry while a second handle runs the same stream in order on another stream: every buffer
+    bit-equal (scratch/soak.py runs the long version over C2, C3 and TONES)."""
+    import torch
+    monkeypatch.setenv("GSDR_DDC_MFMA", "1")
+    N, rate, M, F, L = 256, 200_000_000, 100, 4, 1_000_000
+    rng = np.random.default_rng(8)
+    freq = rng.choice(np.arange(-rate // 2 + 1, rate // 2), size=N, replace=False)
+    a, b = make_direct(freq, rate, M, F, L), make_direct(freq, rate, M, F, L)
+    gen = torch.Generator(device=cuda_device).manual_seed(5)
+    bufs = [torch.view_as_complex(torch.randn(L, 2, device=cuda_device, generator=gen)) * sc
+            for sc in (1e-3, 1.0, 40.0, 1.0, 1e-2, 5.0)]
+    out_a = torch.empty(a.out_capacity, dtype=torch.complex64, device=cuda_device)
+    outs = [torch.empty_like(out_a) for _ in range(3)]
+
+    def fingerprint(t):
+        return torch.view_as_real(t).view(torch.int32).sum(dtype=torch.int64)
+
+    torch.cuda.synchronize()
+    pend, bad = [], []
+    for k in range(400):
+        n = a.process_device(bufs[k % 6], out_a)
+        fp = fingerprint(out_a[:n])
+        if len(pend) == 3:
+            kk, want = pend.pop(0)
+            m = b.wait()
+            if fingerprint(outs[kk % 3][:m]).item() != want.item():
+                bad.append(kk)
+        b.submit_device(bufs[k % 6], outs[k % 3])
+        pend.append((k, fp))
+    while pend:
+        kk, want = pend.pop(0)
+        m = b.wait()
+        if fingerprint(outs[kk % 3][:m]).item() != want.item():
+            bad.append(kk)
+    assert not bad, bad
+    a.close()
+    b.close()
+
+
 def test_profile_sampling(cuda_device, gsdr_lib):
     """gsdr_demod_profile_enable(n): hipEvents around every n-th launch of the dominant kernel."""
     import torch
