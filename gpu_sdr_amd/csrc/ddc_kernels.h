@@ -107,7 +107,6 @@ void mfma_build_tables(const MfmaPlan &pl, const std::vector<unsigned> &fmod_in,
                        std::vector<uint4> &bfrag, std::vector<float2> &ptab,
                        std::vector<float2> &dtab, std::vector<float> &taps,
                        std::vector<unsigned> &fmod, float &unscale);
-void mfma3_build_bfrag(const MfmaPlan &pl, const std::vector<unsigned> &fmod, std::vector<uint4> &bfrag);
 hipError_t launch_absmax(const float2 *x, long long n, unsigned *slots, int cur, int next,
                          float2 *head_cur, long long head_n, float2 *head_next, int carry_len,
                          float2 *tail, long long tail0, hipStream_t st, const float2 *extra_src = nullptr,
@@ -115,7 +114,7 @@ hipError_t launch_absmax(const float2 *x, long long n, unsigned *slots, int cur,
 // AsmRing: assembly main loop, operand shared through an LDS ring (production);
 // AsmSolo: assembly main loop, every wave converts its own operand; Cxx: compiler-scheduled
 // (TT, PK, W apply to it only; the assembly kernels are TT = 1, PK = 32, W = 4).
-enum class MfmaKernel { AsmRing, AsmSolo, Cxx, AsmRingDirect, Cxx3 };
+enum class MfmaKernel { AsmRing, AsmSolo, Cxx, AsmRingDirect };
 hipError_t launch_ddc_mfma(MfmaKernel kind, int TT, int PK, int W, const MfmaLaunch &a, hipStream_t st);
 const char *ddc_mfma_kernel_name(MfmaKernel kind);
 

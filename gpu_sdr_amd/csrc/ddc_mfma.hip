@@ -317,143 +317,6 @@ __global__ __launch_bounds__(64 * W, TT == 1 ? 2 : 1) void ddc_mfma_kernel(const
     store_rows<TT>(a, gt, n0, hh, invS, accr, acci);
 }
 
-// The three-multiplication form of the inner complex product (Karatsuba/Gauss), compiler
-// scheduled like ddc_mfma_kernel; an experiment in MFMA count, GSDR_MFMA_ASM=4.  With
-// b = br + i bi (input x taps, tone independent) and W = Wr + i Wi (phasor table):
-//     T1 = sum (br + bi) Wr,   T2 = sum br (Wi - Wr),   T3 = sum bi (Wr + Wi)
-//     Re sum b W = T1 - T3,    Im sum b W = T1 + T2
-// i.e. three real GEMMs whose K runs over 16 SAMPLES per v_mfma_f32_32x32x16_f16 instead of two
-// whose K runs over 8 samples x (re, im): 18 MFMAs per block of 32 samples instead of 24.  Each
-// real operand is still split into fp16 hi + lo (three products per multiplication).  Price: a
-// third operand stream in the conversion and in the LDS ring (12 KiB per block instead of 8), a
-// third result matrix, 96 instead of 64 FMAs in the rotation, and the cancellation in T1 - T3.
-//
-// Ring layout: [slot][16-sample step][stream: br+bi, br, bi][hi, lo][consumer lane] x 16 B; wave w
-// converts samples 8w .. 8w+7 of the block, its lane (row, hh) the four samples 4hh .. 4hh+3 of
-// those: 8 bytes into the slot of consumer lane (row, w & 1) at byte 8*hh.
-__global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops"))) void ddc_mfma3_kernel(
-    const MfmaLaunch a) {
-    constexpr int W = 4, KS = 2;
-    __shared__ uint4 ring[2][KS][3][2][64];
-    const MfmaShape &sh = a.sh;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int r = lane & 31, hh = lane >> 5;
-    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-    const int gt = (q / sh.ntq) * 8 + xcd;
-    if (gt >= sh.ngt) return;
-    const int tg_raw = (q % sh.ntq) * W + wave;
-    const bool active = tg_raw < sh.ntg;
-    const int tg = active ? tg_raw : sh.ntg - 1;
-
-    half8 Bf[KS][3][2];   // [step][Wr, Wi - Wr, Wr + Wi][hi, lo]
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-        for (int m = 0; m < 3; ++m)
-#pragma unroll
-            for (int sp = 0; sp < 2; ++sp)
-                Bf[ks][m][sp] = __builtin_bit_cast(half8, a.bfrag[((((size_t)tg * KS + ks) * 3 + m) * 2 + sp) * 64 + lane]);
-
-    const unsigned mb = slot_max(a.maxbits, sh.slot_cur, sh.slot_prev);
-    int se = 139 - (int)((mb >> 23) & 0xffu);       // |b| < 2^13: br + bi stays below 2^14
-    se = se > 100 ? 100 : (se < -100 ? -100 : se);
-    const float S = bits_to_float((unsigned)(127 + se) << 23);
-    const float invS = bits_to_float((unsigned)(127 - se) << 23) * sh.unscale;
-
-    const int o = gt * 32 + r;
-    const int oc = o < sh.nout ? o : sh.nout - 1;
-    const float2 *xbase = gt == 0 ? a.head + sh.carry_len
-                                  : (gt == sh.ngt - 1 ? a.tail - sh.tail0 : a.x);
-    const float2 *xrow = xbase + ((long long)(oc + sh.woff) * sh.M + 4 * hh);
-    const float *tp = a.taps + 4 * hh;
-    const int nhi = (sh.nk8 + 3) / 4;
-    float4v xa, xb, hv;
-    auto gload = [&](int blk) __attribute__((always_inline)) {
-        const int bc = blk < nhi ? blk : nhi - 1;
-        const int k = bc * 4 + wave;
-        hv = *reinterpret_cast<const float4v *>(tp + 8 * k);
-        const float4u *p = reinterpret_cast<const float4u *>(xrow + 8 * k);
-        xa = p[0];
-        xb = p[1];
-    };
-    auto produce = [&](int slot) __attribute__((always_inline)) {
-        const float4v hs = hv * S;
-        const float vr[4] = {xa.x * hs.x, xa.z * hs.y, xb.x * hs.z, xb.z * hs.w};
-        const float vi[4] = {xa.y * hs.x, xa.w * hs.y, xb.y * hs.z, xb.w * hs.w};
-#pragma unroll
-        for (int st = 0; st < 3; ++st) {
-            half4v h, l;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float v = st == 0 ? vr[j] + vi[j] : (st == 1 ? vr[j] : vi[j]);
-                h[j] = (_Float16)v;
-                l[j] = (_Float16)(v - (float)h[j]);
-            }
-            uint2 *dh = reinterpret_cast<uint2 *>(&ring[slot][wave >> 1][st][0][(wave & 1) * 32 + r]);
-            uint2 *dl = reinterpret_cast<uint2 *>(&ring[slot][wave >> 1][st][1][(wave & 1) * 32 + r]);
-            dh[hh] = __builtin_bit_cast(uint2, h);
-            dl[hh] = __builtin_bit_cast(uint2, l);
-        }
-    };
-
-    float16v accr, acci;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) accr[i] = acci[i] = 0.f;
-    const int Np = sh.NT32 * 32;
-    const int n0 = tg * 32 + r;
-    const float2 *pp = a.ptab + n0;
-
-    gload(0);
-    produce(0);
-    gload(1);
-    for (int hi = 0; hi < nhi; ++hi) {
-        const int slot = hi & 1;
-        wg_barrier();
-        half8 fh[KS][3], fl[KS][3];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-            for (int st = 0; st < 3; ++st) {
-                fh[ks][st] = __builtin_bit_cast(half8, ring[slot][ks][st][0][lane]);
-                fl[ks][st] = __builtin_bit_cast(half8, ring[slot][ks][st][1][lane]);
-            }
-        const float2 P = pp[(size_t)hi * Np];
-        produce(slot ^ 1);
-        gload(hi + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        float16v T[3];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const float16v zero = {0};
-#pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                float16v t = ks == 0 ? zero : T[m];
-                t = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ks][m], Bf[ks][m][0], t, 0, 0, 0);
-                t = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[ks][m], Bf[ks][m][1], t, 0, 0, 0);
-                t = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[ks][m], Bf[ks][m][0], t, 0, 0, 0);
-                T[m] = t;
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_nop 15\n\ts_nop 15");   // results first, then their readers (ddc_mfma_kernel)
-        __builtin_amdgcn_sched_barrier(0);
-        const float pd = P.x - P.y, ps = P.x + P.y;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            accr[i] = __builtin_fmaf(pd, T[0][i], accr[i]);
-            accr[i] = __builtin_fmaf(-P.x, T[2][i], accr[i]);
-            accr[i] = __builtin_fmaf(-P.y, T[1][i], accr[i]);
-            acci[i] = __builtin_fmaf(ps, T[0][i], acci[i]);
-            acci[i] = __builtin_fmaf(P.x, T[1][i], acci[i]);
-            acci[i] = __builtin_fmaf(-P.y, T[2][i], acci[i]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if (!active) return;
-    store_tile(a, gt, n0, hh, invS, tile_phasor(a, gt, a.fmod[n0]), accr, acci);
-}
-
 // The same arithmetic with the main loop in assembly (tools/gen_ddc_mfma.py): one
 // tone tile per wave, four independent waves per workgroup (no LDS ring, no barrier
 // in the loop: every wave converts its own A operand; the workgroup shares only the
@@ -983,39 +846,6 @@ void mfma_build_tables(const MfmaPlan &pl, const std::vector<unsigned> &fmod_in,
     for (int t = 0; t < pl.MF; ++t) taps[t] = std::ldexp(window[t], -eh);
 }
 
-// Phasor-table operand images of ddc_mfma3_kernel: per 32-tone tile, 16-sample step ks and
-// matrix m in (Wr, Wi - Wr, Wr + Wi), fp16 hi and lo: lane (n, hh), element j  <->  sample
-// lo = 16*ks + 8*hh + j of the block, tone 32*tile + n.
-void mfma3_build_bfrag(const MfmaPlan &pl, const std::vector<unsigned> &fmod, std::vector<uint4> &bfrag) {
-    const int tiles = pl.ntg * pl.TT;
-    const unsigned rate = pl.rate;
-    bfrag.assign((size_t)tiles * 2 * 3 * 2 * 64, uint4{0, 0, 0, 0});
-    for (int T = 0; T < tiles; ++T)
-        for (int ks = 0; ks < 2; ++ks)
-            for (int lane = 0; lane < 64; ++lane) {
-                const int n = lane & 31, hh = lane >> 5;
-                const unsigned long long fm = fmod[(size_t)T * 32 + n];
-                unsigned short img[3][2][8];
-                for (int j = 0; j < 8; ++j) {
-                    const int lo = 16 * ks + 8 * hh + j;
-                    double wr, wi;
-                    host_phasor((fm * (unsigned long long)lo) % rate, rate, wr, wi);
-                    const float v[3] = {(float)wr, (float)(wi - wr), (float)(wr + wi)};
-                    for (int m = 0; m < 3; ++m) {
-                        const unsigned short hb = to_half_bits(v[m]);
-                        img[m][0][j] = hb;
-                        img[m][1][j] = to_half_bits(v[m] - from_half_bits(hb));
-                    }
-                }
-                for (int m = 0; m < 3; ++m)
-                    for (int sp = 0; sp < 2; ++sp) {
-                        uint4 w;
-                        __builtin_memcpy(&w, img[m][sp], 16);
-                        bfrag[((((size_t)T * 2 + ks) * 3 + m) * 2 + sp) * 64 + lane] = w;
-                    }
-            }
-}
-
 hipError_t launch_absmax(const float2 *x, long long n, unsigned *slots, int cur, int next,
                          float2 *head_cur, long long head_n, float2 *head_next, int carry_len,
                          float2 *tail, long long tail0, hipStream_t st, const float2 *extra_src,
@@ -1072,14 +902,6 @@ hipError_t launch_ddc_mfma(MfmaKernel kind, int TT, int PK, int W, const MfmaLau
         hipLaunchKernelGGL(ddc_mfma_ringd_kernel, dim3((unsigned)grid), dim3(256), 0, st, a);
         return hipGetLastError();
     }
-    if (kind == MfmaKernel::Cxx3) {
-        if (TT != 1 || PK != 32 || W != 4) return hipErrorInvalidValue;
-        const int gt8 = (sh.ngt + 7) / 8;
-        const long long grid = (long long)gt8 * 8 * sh.ntq;
-        if (grid < 1 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(ddc_mfma3_kernel, dim3((unsigned)grid), dim3(256), 0, st, a);
-        return hipGetLastError();
-    }
     if (kind == MfmaKernel::AsmRing) {
         if (TT != 1 || PK != 32 || W != 4) return hipErrorInvalidValue;
         const int gt8 = (sh.ngt + 7) / 8;
@@ -1105,7 +927,7 @@ hipError_t launch_ddc_mfma(MfmaKernel kind, int TT, int PK, int W, const MfmaLau
 }
 
 const char *ddc_mfma_kernel_name(MfmaKernel kind) {
-    return kind == MfmaKernel::Cxx3 ? "ddc_mfma3_kernel" : kind == MfmaKernel::AsmRingDirect ? "ddc_mfma_ringd_kernel" : kind == MfmaKernel::AsmRing ? "ddc_mfma_ring_kernel" : kind == MfmaKernel::AsmSolo ? "ddc_mfma_asm_kernel" : "ddc_mfma_kernel";
+    return kind == MfmaKernel::AsmRingDirect ? "ddc_mfma_ringd_kernel" : kind == MfmaKernel::AsmRing ? "ddc_mfma_ring_kernel" : kind == MfmaKernel::AsmSolo ? "ddc_mfma_asm_kernel" : "ddc_mfma_kernel";
 }
 
 }  // namespace gsdr

@@ -391,10 +391,7 @@ int setup_mfma(gsdr_demod *h, bool direct, const std::vector<long long> &tone) {
     std::vector<float> taps;
     std::vector<unsigned> fmod;
     float unscale = 1.f;
-    // 4 = the three-multiplication form of the complex product, compiler scheduled (experiment)
-    if (asm_kind == 4 && asm_shape) h->mf_kind = gsdr::MfmaKernel::Cxx3;
     gsdr::mfma_build_tables(pl, fmod_in, h->window.data(), bfrag, ptab, dtab, taps, fmod, unscale);
-    if (h->mf_kind == gsdr::MfmaKernel::Cxx3) gsdr::mfma3_build_bfrag(pl, fmod, bfrag);
     HIPCHK(h, upload(&h->d_bfrag, bfrag));
     HIPCHK(h, upload(&h->d_ptab, ptab));
     HIPCHK(h, upload(&h->d_dtab, dtab));

@@ -136,7 +136,7 @@ DIRECT_CASES = [
 
 @pytest.mark.parametrize("case", DIRECT_CASES, ids=lambda c: "N%d_M%d_F%d_L%d" % (c[0], c[2], c[3], c[4]))
 @pytest.mark.parametrize("impl", ["flat", "flat12", "flat16", "flat20", "simple16", "simple32",
-                                  "mfma", "mfma_direct", "mfma_g3", "mfma_solo", "mfma_c", "mfma_t2", "mfma_w2", "mfma_pk16"])
+                                  "mfma", "mfma_direct", "mfma_solo", "mfma_c", "mfma_t2", "mfma_w2", "mfma_pk16"])
 def test_direct_parity(cuda_device, gsdr_lib, oracle_mod, monkeypatch, case, impl):
     """flat* = ddc_flat_kernel (packed FP32; sub-block length auto / forced),
     simple* = ddc_kernel (generic fallback, phasor table 16 / 32),
@@ -144,8 +144,6 @@ def test_direct_parity(cuda_device, gsdr_lib, oracle_mod, monkeypatch, case, imp
     shared through an LDS ring: the production kernel),
     mfma_direct = ddc_mfma_ringd_kernel (the same loop reading buffer and carry in place: one
     launch per buffer, one scale per workgroup; M % 4 == 0, other shapes run the staged kernel),
-    mfma_g3 = ddc_mfma3_kernel (three-multiplication complex product: 18 instead of 24 MFMAs per
-    block, compiler scheduled; an experiment, GSDR_MFMA_ASM=4),
     mfma_solo = ddc_mfma_asm_kernel (assembly main loop, every wave converts its own operand),
     mfma_c* = ddc_mfma_kernel (same algorithm, compiler-scheduled; tone tiles per wave 1/2,
     waves per workgroup 4/2, phasor block 32/16)."""
@@ -156,8 +154,6 @@ def test_direct_parity(cuda_device, gsdr_lib, oracle_mod, monkeypatch, case, imp
             monkeypatch.setenv("GSDR_MFMA_ASM", "2")
         if impl == "mfma_direct":
             monkeypatch.setenv("GSDR_MFMA_ASM", "3")
-        if impl == "mfma_g3":
-            monkeypatch.setenv("GSDR_MFMA_ASM", "4")
         if impl == "mfma_solo":
             monkeypatch.setenv("GSDR_MFMA_ASM", "1")
         if impl in ("mfma_c", "mfma_t2", "mfma_w2", "mfma_pk16"):
