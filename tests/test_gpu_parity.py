@@ -637,7 +637,7 @@ def test_device_sources_match_their_formulas(cuda_device, gsdr_lib, oracle_mod):
     np.testing.assert_allclose(x.cpu().numpy(), oracle_mod.chirp_gen(ocp, 6500, n, 0.5), rtol=0, atol=3e-7)
 
 
-def test_pipelined_submit_wait_equals_process(cuda_device, gsdr_lib):
+def test_pipelined_submit_wait_equals_process(cuda_device, gsdr_lib, engine):
     """gsdr_demod_submit/_wait (overlapped H2D / kernels / D2H) must give exactly
     what the synchronous process() gives, in order, for every mode."""
     import torch
