@@ -26,6 +26,9 @@ import os
 import sys
 
 DIRECT = "--direct" in sys.argv
+# timing-only builds (WRONG results): GEN_ABLATE=rot,prod,lds drops the rotation FMAs / the
+# conversion arithmetic / the operand reads of the ring from the loop
+ABLATE = set(filter(None, os.environ.get("GEN_ABLATE", "").split(",")))
 KS = 4                     # k-steps per block (PK = 32)
 SLOT = KS * 2 * 1024       # bytes of one ring slot
 
@@ -313,7 +316,9 @@ def iteration(cnt, out, cur, prev, p_cur, p_prev, label):
             cnt.need_lgkm(f"f{ks}l")
         out.append(mfma(cur, ks, m))
         for kind, text, tag in gaps[g]:
-            if kind == "lds" or kind == "ldsw":
+            if kind == "lds" and "lds" in ABLATE:
+                pass
+            elif kind == "lds" or kind == "ldsw":
                 out.append(text)
                 cnt.issue_lgkm(tag)
             elif kind == "vm":
@@ -323,12 +328,14 @@ def iteration(cnt, out, cur, prev, p_cur, p_prev, label):
                 if first_rot:
                     cnt.need_vm("pB" if label == "A" else "pA")
                     first_rot = False
-                out.append(text)
+                if "rot" not in ABLATE:
+                    out.append(text)
             elif kind == "prod":
                 if first_prod:
                     cnt.need_vm("xb")
                     first_prod = False
-                out.append(text)
+                if "prod" not in ABLATE:
+                    out.append(text)
             elif kind == "gload":
                 gload_ops(cnt, out, label)
             else:
