@@ -4,7 +4,7 @@
 # samples rocm-smi meanwhile.
 set -e
 cp gpu_sdr_amd/csrc/ddc_mfma_ring_gen.h /tmp/ring_gen_saved.h
-for ab in none rot prod lds rot,prod rot,prod,lds; do
+for ab in ${ABLATIONS:-none rot prod lds gload bar rot,prod rot,prod,lds rot,prod,lds,gload}; do
   if [ $ab = none ]; then cp /tmp/ring_gen_saved.h gpu_sdr_amd/csrc/ddc_mfma_ring_gen.h; else GEN_ABLATE=$ab python3 tools/gen_ddc_mfma_ring.py > gpu_sdr_amd/csrc/ddc_mfma_ring_gen.h; fi
   make -C gpu_sdr_amd/csrc > /tmp/make.log 2>&1 || { tail -5 /tmp/make.log; exit 1; }
   python bench.py --workload c3 --api inorder --no-extras --no-cpu --steps 20000 --warmup 50 > /tmp/b.json 2>/dev/null &

@@ -26,8 +26,9 @@ import os
 import sys
 
 DIRECT = "--direct" in sys.argv
-# timing-only builds (WRONG results): GEN_ABLATE=rot,prod,lds drops the rotation FMAs / the
-# conversion arithmetic / the operand reads of the ring from the loop
+# timing-only builds (WRONG results): GEN_ABLATE=rot,prod,lds,gload,bar drops the rotation FMAs /
+# the conversion arithmetic / the operand reads of the ring / the input loads / the barrier from
+# the loop
 ABLATE = set(filter(None, os.environ.get("GEN_ABLATE", "").split(",")))
 KS = 4                     # k-steps per block (PK = 32)
 SLOT = KS * 2 * 1024       # bytes of one ring slot
@@ -337,11 +338,13 @@ def iteration(cnt, out, cur, prev, p_cur, p_prev, label):
                 if "prod" not in ABLATE:
                     out.append(text)
             elif kind == "gload":
-                gload_ops(cnt, out, label)
+                if "gload" not in ABLATE:
+                    gload_ops(cnt, out, label)
             else:
                 out.append(text)
     cnt.drain_lgkm()
-    out.append("s_barrier")
+    if "bar" not in ABLATE:
+        out.append("s_barrier")
 
 
 def generate():
@@ -446,7 +449,7 @@ def generate():
     o(f"s_sub_u32 s{S_NLEFT}, s{S_NLEFT}, 1")
     o(f"s_cmp_lg_u32 s{S_NLEFT}, 0")
     o("s_cbranch_scc1 1b")
-    if True:
+    if "gload" not in ABLATE:
         assert cnt.lgkm == [] and cnt.vm == ["prB", "pB"] + XL, (cnt.lgkm, cnt.vm)
         assert state_a == ([], ["prA", "pA"] + XL), state_a
     # exits: P*C of the last block
