@@ -821,6 +821,29 @@ def test_pipelined_soak_full_size(cuda_device, gsdr_lib, monkeypatch):
     b.close()
 
 
+def test_pipelined_entry_limits(cuda_device, gsdr_lib):
+    """At most GSDR_PIPELINE_DEPTH (4) buffers outstanding; wait() without one is an error;
+    after draining, the synchronous entry works on the same handle."""
+    import torch
+    import gpu_sdr_amd as g
+    dem = make_direct([1000, -2500, 77777], 1_000_000, 100, 4, 20_000)
+    x = torch.zeros(20_000, dtype=torch.complex64, device=cuda_device)
+    outs = [torch.empty(dem.out_capacity, dtype=torch.complex64, device=cuda_device) for _ in range(5)]
+    torch.cuda.synchronize()
+    with pytest.raises(g.GsdrError):
+        dem.wait()
+    for k in range(4):
+        dem.submit_device(x, outs[k])
+    with pytest.raises(g.GsdrError, match="pipeline full"):
+        dem.submit_device(x, outs[4])
+    assert [dem.wait() for _ in range(4)] == [3 * 200] * 4
+    with pytest.raises(g.GsdrError):
+        dem.wait()
+    y = run_host(dem, np.zeros(20_000, np.complex64))
+    assert y.size == 600 and np.abs(y).max() == 0
+    dem.close()
+
+
 def test_profile_sampling(cuda_device, gsdr_lib):
     """gsdr_demod_profile_enable(n): hipEvents around every n-th launch of the dominant kernel."""
     import torch
