@@ -110,7 +110,7 @@ struct gsdr_demod {
     // pipelined entries (gsdr_demod_submit*): consecutive DIRECT calls go to two compute
     // streams in turn, so that their kernels overlap (see pipeline_compute)
     hipStream_t s_main[kPipeStreams] = {};
-    int pipe_streams = 2;              // how many of them are used (GSDR_PIPE_STREAMS)
+    int pipe_streams = kPipeStreams;   // how many of them are used (GSDR_PIPE_STREAMS)
     hipEvent_t ev_abs[4] = {nullptr, nullptr, nullptr, nullptr};    // staging pass of call j done
     bool pipe_overlap = false;         // set around the compute of an overlapped call
     unsigned long long pipe_seq = 0;   // overlapped calls so far
@@ -1061,17 +1061,32 @@ static int pipeline_init(gsdr_demod *h) {
         HIPCHK(h, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
         HIPCHK(h, hipEventCreateWithFlags(&sl.down, hipEventDisableTiming));
     }
-    // The two compute streams must sit on different hardware queues to overlap.  HIP deals the
+    // The compute streams must sit on different hardware queues to overlap.  HIP deals the
     // streams of one priority class out to few queues (4 by default) that every other stream
-    // of that class in the process shares too (torch alone creates dozens): which two streams
-    // end up together is luck.  The low-priority class is ours alone, and low priority is what
-    // the reference gives its demodulator stream (cpp/USRP_demodulator.cpp:44).
+    // of that class in the process shares too (torch alone creates dozens), and which streams
+    // end up together is luck (measured: 53 vs 33 us per C2 buffer from run to run, and again
+    // with the second handle of a process).  A stream created with a compute-unit mask gets a
+    // queue of its own: ask for one with every unit enabled.  GSDR_PIPE_QUEUES=0 (or a runtime
+    // that refuses) falls back to streams of the low-priority class, which is what the
+    // reference gives its demodulator stream (cpp/USRP_demodulator.cpp:43-44).
     int prio_least = 0, prio_greatest = 0;
     HIPCHK(h, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-    for (int i = 0; i < kPipeStreams; ++i)
+    hipDeviceProp_t prop;
+    int dev = 0;
+    HIPCHK(h, hipGetDevice(&dev));
+    HIPCHK(h, hipGetDeviceProperties(&prop, dev));
+    std::vector<uint32_t> all_units((size_t)(prop.multiProcessorCount + 31) / 32, 0xffffffffu);
+    if (prop.multiProcessorCount % 32) all_units.back() = (1u << (prop.multiProcessorCount % 32)) - 1u;
+    const bool own_queues = env_int("GSDR_PIPE_QUEUES", 1) != 0;
+    for (int i = 0; i < kPipeStreams; ++i) {
+        if (own_queues &&
+            hipExtStreamCreateWithCUMask(&h->s_main[i], (uint32_t)all_units.size(), all_units.data()) == hipSuccess)
+            continue;
+        (void)hipGetLastError();
         HIPCHK(h, hipStreamCreateWithPriority(&h->s_main[i], hipStreamNonBlocking, prio_least));
-    h->pipe_streams = env_int("GSDR_PIPE_STREAMS", 2);
-    if (h->pipe_streams < 1 || h->pipe_streams > kPipeStreams) h->pipe_streams = 2;
+    }
+    h->pipe_streams = env_int("GSDR_PIPE_STREAMS", kPipeStreams);
+    if (h->pipe_streams < 1 || h->pipe_streams > kPipeStreams) h->pipe_streams = kPipeStreams;
     for (int i = 0; i < 4; ++i) HIPCHK(h, hipEventCreateWithFlags(&h->ev_abs[i], hipEventDisableTiming));
     return 0;
 }
@@ -1080,7 +1095,7 @@ static int pipeline_init(gsdr_demod *h) {
 // becomes ready with (nullptr: it is ready).
 //
 // DIRECT on the staged matrix-core kernel: call j runs on compute stream j % S (S =
-// GSDR_PIPE_STREAMS, 2 by default, at most kPipeStreams), so the kernels of consecutive buffers
+// GSDR_PIPE_STREAMS, kPipeStreams = 3 by default), so the kernels of consecutive buffers
 // overlap and the next buffer fills the compute units that the last workgroups of this one
 // leave idle.  What call j needs from its neighbours:
 //   - its staging pass follows the pass of call j-1 (which wrote the carry in front of this

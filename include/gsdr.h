@@ -101,8 +101,8 @@ int gsdr_demod_wait(gsdr_demod *h);
 /* The same pipeline for a device-resident source (a synthetic generator, a GPU-direct
  * receiver): in_dev must be complete when the call is made, out_dev must be a different
  * buffer for every outstanding call; gsdr_demod_wait() returns when out_dev is complete.
- * Both submit entries run the DIRECT kernels of consecutive buffers on two streams in
- * turn: the next buffer starts on the compute units the last workgroups of this one
+ * Both submit entries run the DIRECT and TONES/NOISE kernels of consecutive buffers on
+ * three streams in turn: the next buffer starts on the compute units the last workgroups of this one
  * leave idle (GSDR_PIPE_OVERLAP=0: strictly one after the other). */
 int gsdr_demod_submit_device(gsdr_demod *h, const gsdr_c64 *in_dev, gsdr_c64 *out_dev);
 
