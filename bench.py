@@ -363,8 +363,8 @@ def rooflines(wl, r, key):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--api", default="auto", choices=["auto", "inorder", "pipelined"],
                     help="entry the timed steps go through; auto = pipelined for the DDC (DIRECT, TONES) workloads")
