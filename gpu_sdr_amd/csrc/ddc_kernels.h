@@ -79,6 +79,7 @@ struct MfmaShape {
     unsigned idx_base;         // NCO index of sample woff*M (mod rate)
     int slot_cur, slot_prev;   // absmax slots of this and the previous buffer
     float unscale;             // power of two the taps were divided by
+    int rt;                    // ring kernel: row tiles a workgroup does one after the other (0, 1: one)
     int timing_mode;           // GSDR_MFMA_TIMING (wrong results): 1 = no stores, 2 = one block only, 3 = both
 };
 

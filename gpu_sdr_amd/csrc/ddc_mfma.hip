@@ -424,29 +424,32 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
 // (tools/gen_ddc_mfma_ring.py): each wave converts one k-step of every block, all
 // four read every k-step back.  A quarter of the loads and conversions of the
 // kernel above, one s_barrier per block.
-__global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops"))) void ddc_mfma_ring_kernel(
-    const MfmaLaunch a) {
-    constexpr int KS = 4, W = 4;
-    // ring (3 slots of 8 KiB) while the loop runs, then the accumulators (4 waves x 8 KiB)
-    __shared__ uint4 lds[2048];
-    static_assert(sizeof(uint4) * 2048 >= GSDR_MFMA_RING_BYTES, "ring fits");
+// One row tile of ddc_mfma_ring_kernel: the assembly loop and the stores.  `first`: load the
+// phasor images (the second tile of a workgroup keeps them).
+__device__ __forceinline__ __attribute__((target("no-packed-fp32-ops"))) void ring_tile(
+    const MfmaLaunch &a, uint4 *lds, int gt, int first, unsigned fm, int se, int tg, int wave, bool active) {
+    constexpr int KS = 4;
     const MfmaShape &sh = a.sh;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int Np = sh.NT32 * 32;
+    const int nhi = (sh.timing_mode & 2) ? 1 : (sh.nk8 + KS - 1) / KS;
+    // Everything per lane is derived again for every tile, from an id the compiler cannot see
+    // through: it has twelve registers of its own across the assembly (v0..v11), and what it
+    // would carry over from the first tile it would have to park in AGPRs.
+    unsigned tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = (int)(tid & 63u);
     const int r = lane & 31, hh = lane >> 5;
-    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-    const int gt = (q / sh.ntq) * 8 + xcd;
-    if (gt >= sh.ngt) return;
-    const int tg_raw = (q % sh.ntq) * W + wave;
-    const bool active = tg_raw < sh.ntg;
-    const int tg = active ? tg_raw : sh.ntg - 1;
-
-    const unsigned mb = slot_max(a.maxbits, sh.slot_cur, sh.slot_prev);
-    int se = 140 - (int)((mb >> 23) & 0xffu);
-    se = se > 100 ? 100 : (se < -100 ? -100 : se);
     const float S = bits_to_float((unsigned)(127 + se) << 23);
-    const float invS = bits_to_float((unsigned)(127 - se) << 23) * sh.unscale;
-
+    const unsigned to = (unsigned)((4 * hh + 8 * wave) * 4);
+    const int n0 = tg * 32 + r;
+    const unsigned po = (unsigned)n0 * 8u;
+    const unsigned bo = (unsigned)tg * (KS * 4 * 1024u) + (unsigned)lane * 16u;
+    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char *)lds;
+    const unsigned lane16 = lds_base + (unsigned)lane * 16u;
+    const unsigned wr16 = lane16 + (unsigned)wave * 2048u;
+    const unsigned accaddr = lds_base + (unsigned)wave * 8192u + (unsigned)lane * 16u;
+    const unsigned long long tpb = (unsigned long long)a.taps, ppb = (unsigned long long)a.ptab,
+                             bfb = (unsigned long long)a.bfrag;
     const int o = gt * 32 + r;
     const int oc = o < sh.nout ? o : sh.nout - 1;
     const float2 *xbase;
@@ -463,19 +466,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
     }
     // this wave converts k-step `wave` of every block: 8 samples = 64 bytes further on
     const unsigned xo = (unsigned)((((long long)(oc + sh.woff) * sh.M + xshift) + 4 * hh + 8 * wave) * 8);
-    const unsigned to = (unsigned)((4 * hh + 8 * wave) * 4);
-    const int Np = sh.NT32 * 32;
-    const int n0 = tg * 32 + r;
-    const unsigned po = (unsigned)n0 * 8u;
-    const unsigned bo = (unsigned)tg * (KS * 4 * 1024u) + (unsigned)lane * 16u;
-    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char *)lds;
-    const unsigned lane16 = lds_base + (unsigned)lane * 16u;
-    const unsigned wr16 = lane16 + (unsigned)wave * 2048u;
-    const unsigned accaddr = lds_base + (unsigned)wave * 8192u + (unsigned)lane * 16u;
-    const unsigned long long xb = (unsigned long long)xbase, tpb = (unsigned long long)a.taps,
-                             ppb = (unsigned long long)a.ptab, bfb = (unsigned long long)a.bfrag;
-    const int nhi = (sh.timing_mode & 2) ? 1 : (sh.nk8 + KS - 1) / KS;
-    const unsigned fm = a.fmod[n0];
+    const unsigned long long xb = (unsigned long long)xbase;
     asm volatile(GSDR_MFMA_RING_TEXT
                  :
                  : [xo] "v"(xo), [to] "v"(to), [po] "v"(po), [bo] "v"(bo), [lane16] "v"(lane16), [wr16] "v"(wr16),
@@ -489,23 +480,61 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
                    [bf_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(bfb >> 32))),
                    [pstride] "s"(__builtin_amdgcn_readfirstlane((int)((unsigned)Np * 8u))),
                    [nhi] "s"(__builtin_amdgcn_readfirstlane(nhi)),
+                   [first] "s"(__builtin_amdgcn_readfirstlane(first)),
                    [scale] "v"(S),
                    // not read by the loop: an operand only so that the load is issued in front of it
                    [fm] "v"(fm)
                  : GSDR_MFMA_RING_CLOBBERS);
-    if (!active || (sh.timing_mode & 1)) return;
-    float16v accr[1], acci[1];
-    const float4v *acc = reinterpret_cast<const float4v *>(lds) + wave * 512 + lane;
+    if (active && !(sh.timing_mode & 1)) {
+        unsigned tid2 = threadIdx.x;
+        asm volatile("" : "+v"(tid2));
+        const int lane2 = (int)(tid2 & 63u);
+        const float invS = bits_to_float((unsigned)(127 - se) << 23) * sh.unscale;
+        float16v accr, acci;
+        const float4v *acc = reinterpret_cast<const float4v *>(lds) + wave * 512 + lane2;
 #pragma unroll
-    for (int qd = 0; qd < 4; ++qd) {
-        const float4v vr = acc[qd * 64], vi = acc[(qd + 4) * 64];
+        for (int qd = 0; qd < 4; ++qd) {
+            const float4v vr = acc[qd * 64], vi = acc[(qd + 4) * 64];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            accr[0][qd * 4 + j] = vr[j];
-            acci[0][qd * 4 + j] = vi[j];
+            for (int j = 0; j < 4; ++j) {
+                accr[qd * 4 + j] = vr[j];
+                acci[qd * 4 + j] = vi[j];
+            }
         }
+        store_tile(a, gt, tg * 32 + (lane2 & 31), lane2 >> 5, invS, tile_phasor(a, gt, fm), accr, acci);
     }
-    store_tile(a, gt, n0, hh, invS, tile_phasor(a, gt, fm), accr[0], acci[0]);
+}
+
+__global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops"))) void ddc_mfma_ring_kernel(
+    const MfmaLaunch a) {
+    constexpr int W = 4;
+    // ring (3 slots of 8 KiB) while the loop runs, then the accumulators (4 waves x 8 KiB)
+    __shared__ uint4 lds[2048];
+    static_assert(sizeof(uint4) * 2048 >= GSDR_MFMA_RING_BYTES, "ring fits");
+    const MfmaShape &sh = a.sh;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // sh.rt = 2: two row tiles per workgroup, one after the other, both on this workgroup's XCD:
+    // the phasor images (64 KiB per workgroup) and everything up to the scale are loaded once.
+    // (Two calls of the tile code, not a loop: across a loop's back edge the compiler parks what
+    // it keeps in AGPRs -- it has twelve registers of its own beside the assembly -- and the
+    // kernel drops to one wave per SIMD.)
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int rt = sh.rt > 1 ? 2 : 1;
+    const int gt0 = (q / sh.ntq) * rt * 8 + xcd;
+    if (gt0 >= sh.ngt) return;
+    const int tg_raw = (q % sh.ntq) * W + wave;
+    const bool active = tg_raw < sh.ntg;
+    const int tg = active ? tg_raw : sh.ntg - 1;
+    const unsigned mb = slot_max(a.maxbits, sh.slot_cur, sh.slot_prev);
+    int se = 140 - (int)((mb >> 23) & 0xffu);
+    se = se > 100 ? 100 : (se < -100 ? -100 : se);
+    const unsigned fm = a.fmod[tg * 32 + (threadIdx.x & 31)];
+    ring_tile(a, lds, gt0, 1, fm, se, tg, wave, active);
+    if (rt > 1 && gt0 + 8 < sh.ngt) {
+        // the ring of the next tile overlays the accumulators of this one: every wave has read its own
+        workgroup_sync();
+        ring_tile(a, lds, gt0 + 8, 0, fm, se, tg, wave, active);
+    }
 }
 
 // The ring kernel without its staging pass: ONE launch per buffer.  The loop reads the
@@ -903,8 +932,9 @@ hipError_t launch_ddc_mfma(MfmaKernel kind, int TT, int PK, int W, const MfmaLau
         return hipGetLastError();
     }
     if (kind == MfmaKernel::AsmRing) {
-        if (TT != 1 || PK != 32 || W != 4) return hipErrorInvalidValue;
-        const int gt8 = (sh.ngt + 7) / 8;
+        if (TT != 1 || PK != 32 || W != 4 || sh.rt < 0 || sh.rt > 8) return hipErrorInvalidValue;
+        const int rt = sh.rt > 1 ? sh.rt : 1;
+        const int gt8 = ((sh.ngt + 7) / 8 + rt - 1) / rt;   // groups of rt row tiles per XCD
         const long long grid = (long long)gt8 * 8 * sh.ntq;
         if (grid < 1 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
         hipLaunchKernelGGL(ddc_mfma_ring_kernel, dim3((unsigned)grid), dim3(256), 0, st, a);

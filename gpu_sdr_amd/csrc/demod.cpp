@@ -415,6 +415,8 @@ int setup_mfma(gsdr_demod *h, bool direct, const std::vector<long long> &tone) {
     sh.m_mod_rate = (unsigned)M % rate;
     sh.unscale = unscale;
     sh.timing_mode = env_int("GSDR_MFMA_TIMING", 0);
+    sh.rt = env_int("GSDR_MFMA_RT", 0);   // 0: chosen per launch in enqueue_mfma
+    if (sh.rt < 0 || sh.rt > 2) sh.rt = 0;
     if (direct) {
         // row tile 0 and the last row tile read from copies with the carry in front
         // and zeros behind (sizes: ddc_mfma_kernel's reach, 8*nk8 samples per row)
@@ -556,6 +558,16 @@ int enqueue_mfma(gsdr_demod *h, const float2 *in, float2 *raw, long long raw_new
     a.sh.idx_base = idx_base;
     a.sh.slot_cur = cur;
     a.sh.slot_prev = prev;
+    if (a.sh.rt == 0) {
+        // Two row tiles per workgroup (the second keeps the phasor images: 64 KiB less to load, one
+        // preamble less) where the images weigh against a short window -- C2: 16 KiB per wave against
+        // 26 KiB of input -- and enough workgroups remain to fill the chip: in the overlapped entries
+        // the neighbouring launches see to that (C2 30.3 -> 27.9 us per buffer), in order only a
+        // launch of at least two rounds does (C2 in order: 39.1 -> 42.9 us, so not there).
+        const int nblk = (a.sh.nk8 + 3) / 4;
+        const long long wgs = (long long)a.sh.ngt * a.sh.ntq;
+        a.sh.rt = nblk <= 32 && (h->pipe_overlap ? wgs >= 512 : wgs >= 2048) ? 2 : 1;
+    }
     if (raw) {
         // TONES: one pass brings the carried samples to the front of this call's raw window,
         // appends the buffer and takes its maximum; every row reads the window itself

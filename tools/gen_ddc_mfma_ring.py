@@ -26,9 +26,9 @@ import os
 import sys
 
 DIRECT = "--direct" in sys.argv
-# timing-only builds (WRONG results): GEN_ABLATE=rot,prod,lds,gload,bar drops the rotation FMAs /
-# the conversion arithmetic / the operand reads of the ring / the input loads / the barrier from
-# the loop
+# timing-only builds (WRONG results): GEN_ABLATE=rot,prod,lds,gload,bar,bimg drops the rotation
+# FMAs / the conversion arithmetic / the operand reads of the ring / the input loads / the barrier
+# from the loop, the phasor-image loads from the prologue
 ABLATE = set(filter(None, os.environ.get("GEN_ABLATE", "").split(",")))
 KS = 4                     # k-steps per block (PK = 32)
 SLOT = KS * 2 * 1024       # bytes of one ring slot
@@ -382,9 +382,16 @@ def generate():
         o(f"s_add_u32 s{BF[j]}, s{S_BF}, {4096 * j}")
         o(f"s_addc_u32 s{BF[j] + 1}, s{S_BF + 1}, 0")
     o("s_nop 4")
+    # (a workgroup that runs the loop for a second row tile keeps them: %[first] == 0)
+    if not DIRECT:
+        o("s_cmp_eq_u32 %[first], 0")
+        o("s_cbranch_scc1 4f")
     for f in range(16):
         b = BF[f // 4]
-        o(f"global_load_dwordx4 {ar(4 * f)}, %[bo], s[{b}:{b + 1}] offset:{(f % 4) * 1024}")
+        if "bimg" not in ABLATE:
+            o(f"global_load_dwordx4 {ar(4 * f)}, %[bo], s[{b}:{b + 1}] offset:{(f % 4) * 1024}")
+    if not DIRECT:
+        o("4:")
     # zero: C set B, accumulators, P_B
     for base in (CB[0], CB[1], ACC[0], ACC[1]):
         for i in range(16):
