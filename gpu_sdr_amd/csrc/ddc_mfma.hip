@@ -112,8 +112,8 @@ __device__ __forceinline__ unsigned slot_max(const unsigned *slots, int cur, int
 }
 
 // w_n^(idx_base + 32*gt*M): the phasor of tone n (fm = f_n mod rate) at the first row of
-// row tile gt.  The assembly kernels load fm before their main loop (the load then costs
-// nothing) and do the arithmetic behind it, in the shadow of the dtab loads.
+// row tile gt.  Computed behind the loop, in the shadow of the dtab loads (as an operand of the
+// assembly block, to have its load issued in front of the loop, fm costs a full s_waitcnt there).
 __device__ __forceinline__ float2 tile_phasor(const MfmaLaunch &a, int gt, unsigned fm) {
     const MfmaShape &sh = a.sh;
     const unsigned long long s_tile = mod_rate(
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
 // One row tile of ddc_mfma_ring_kernel: the assembly loop and the stores.  `first`: load the
 // phasor images (the second tile of a workgroup keeps them).
 __device__ __forceinline__ __attribute__((target("no-packed-fp32-ops"))) void ring_tile(
-    const MfmaLaunch &a, uint4 *lds, int gt, int first, unsigned fm, int se, int tg, int wave, bool active) {
+    const MfmaLaunch &a, uint4 *lds, int gt, int first, int se, int tg, int wave, bool active) {
     constexpr int KS = 4;
     const MfmaShape &sh = a.sh;
     const int Np = sh.NT32 * 32;
@@ -481,9 +481,7 @@ __device__ __forceinline__ __attribute__((target("no-packed-fp32-ops"))) void ri
                    [pstride] "s"(__builtin_amdgcn_readfirstlane((int)((unsigned)Np * 8u))),
                    [nhi] "s"(__builtin_amdgcn_readfirstlane(nhi)),
                    [first] "s"(__builtin_amdgcn_readfirstlane(first)),
-                   [scale] "v"(S),
-                   // not read by the loop: an operand only so that the load is issued in front of it
-                   [fm] "v"(fm)
+                   [scale] "v"(S)
                  : GSDR_MFMA_RING_CLOBBERS);
     if (active && !(sh.timing_mode & 1)) {
         unsigned tid2 = threadIdx.x;
@@ -501,7 +499,8 @@ __device__ __forceinline__ __attribute__((target("no-packed-fp32-ops"))) void ri
                 acci[qd * 4 + j] = vi[j];
             }
         }
-        store_tile(a, gt, tg * 32 + (lane2 & 31), lane2 >> 5, invS, tile_phasor(a, gt, fm), accr, acci);
+        const int n = tg * 32 + (lane2 & 31);
+        store_tile(a, gt, n, lane2 >> 5, invS, tile_phasor(a, gt, a.fmod[n]), accr, acci);
     }
 }
 
@@ -528,12 +527,11 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
     const unsigned mb = slot_max(a.maxbits, sh.slot_cur, sh.slot_prev);
     int se = 140 - (int)((mb >> 23) & 0xffu);
     se = se > 100 ? 100 : (se < -100 ? -100 : se);
-    const unsigned fm = a.fmod[tg * 32 + (threadIdx.x & 31)];
-    ring_tile(a, lds, gt0, 1, fm, se, tg, wave, active);
+    ring_tile(a, lds, gt0, 1, se, tg, wave, active);
     if (rt > 1 && gt0 + 8 < sh.ngt) {
         // the ring of the next tile overlays the accumulators of this one: every wave has read its own
         workgroup_sync();
-        ring_tile(a, lds, gt0 + 8, 0, fm, se, tg, wave, active);
+        ring_tile(a, lds, gt0 + 8, 0, se, tg, wave, active);
     }
 }
 
@@ -626,7 +624,6 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
     const unsigned long long xb = (unsigned long long)a.x, cb = (unsigned long long)a.head,
                              tpb = (unsigned long long)a.taps, ppb = (unsigned long long)a.ptab,
                              bfb = (unsigned long long)a.bfrag;
-    const unsigned fm = a.fmod[n0];
     asm volatile(GSDR_MFMA_RINGD_TEXT
                  :
                  : [s0] "v"(s0), [to] "v"(to), [po] "v"(po), [bo] "v"(bo), [lane16] "v"(lane16), [wr16] "v"(wr16),
@@ -644,8 +641,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
                    [bf_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(bfb >> 32))),
                    [pstride] "s"(__builtin_amdgcn_readfirstlane((int)((unsigned)Np * 8u))),
                    [nhi] "s"(__builtin_amdgcn_readfirstlane(nhi)),
-                   [scale] "v"(S),
-                   [fm] "v"(fm)
+                   [scale] "v"(S)
                  : GSDR_MFMA_RINGD_CLOBBERS);
     if (!active || (sh.timing_mode & 1)) return;
     float16v accr[1], acci[1];
@@ -659,7 +655,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
             acci[0][qd * 4 + j] = vi[j];
         }
     }
-    store_tile(a, gt, n0, hh, invS, tile_phasor(a, gt, fm), accr[0], acci[0]);
+    store_tile(a, gt, n0, hh, invS, tile_phasor(a, gt, a.fmod[n0]), accr[0], acci[0]);
 }
 
 // One pass over the new buffer x[0..n):
