@@ -560,13 +560,15 @@ int enqueue_mfma(gsdr_demod *h, const float2 *in, float2 *raw, long long raw_new
     a.sh.slot_prev = prev;
     if (a.sh.rt == 0) {
         // Two row tiles per workgroup (the second keeps the phasor images: 64 KiB less to load, one
-        // preamble less) where the images weigh against a short window -- C2: 16 KiB per wave against
-        // 26 KiB of input -- and enough workgroups remain to fill the chip: in the overlapped entries
-        // the neighbouring launches see to that (C2 30.3 -> 27.9 us per buffer), in order only a
-        // launch of at least two rounds does (C2 in order: 39.1 -> 42.9 us, so not there).
+        // preamble less, half as many workgroups).  Measured at decim 100 (13-block windows) for
+        // 128 .. 2048 tones, in order and overlapped (scratch/rt_probe.py): it pays in exactly one
+        // place, a launch of between one and two rounds of workgroups in the overlapped entries
+        // (256 tones, 626 workgroups: 31.3 -> 29.4 us per buffer), where the neighbouring launches
+        // fill the compute units that 313 longer workgroups leave free; everywhere else it is
+        // neutral or costs up to 15 % (in order, few workgroups).
         const int nblk = (a.sh.nk8 + 3) / 4;
         const long long wgs = (long long)a.sh.ngt * a.sh.ntq;
-        a.sh.rt = nblk <= 32 && (h->pipe_overlap ? wgs >= 512 : wgs >= 2048) ? 2 : 1;
+        a.sh.rt = h->pipe_overlap && nblk <= 32 && wgs >= 512 && wgs < 1024 ? 2 : 1;
     }
     if (raw) {
         // TONES: one pass brings the carried samples to the front of this call's raw window,
