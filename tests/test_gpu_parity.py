@@ -850,6 +850,59 @@ def test_pipelined_entry_limits(cuda_device, gsdr_lib):
     dem.close()
 
 
+@pytest.mark.parametrize("rt", ["0", "2"])
+def test_pipelined_fuzz_random_shapes(cuda_device, gsdr_lib, monkeypatch, rt):
+    """Seeded fuzz of the overlapped device entry against the in-order entry, bit for bit:
+    DIRECT and TONES shapes nobody picked by hand (one row tile, partial last tiles, windows of
+    one block, buffers barely longer than the carry, batch counts that change from buffer to
+    buffer), seven buffers each with up to four outstanding."""
+    import torch
+    monkeypatch.setenv("GSDR_DDC_MFMA", "1")
+    monkeypatch.setenv("GSDR_MFMA_RT", rt)
+    rng = np.random.default_rng(4242)
+    ran_mfma = 0
+    for it in range(36):
+        rate = int(rng.choice([1_000_000, 10_000_000, 200_000_000]))
+        N = int(rng.choice([1, 7, 33, 64, 129, 300]))
+        F = int(rng.integers(1, 9))
+        freq = rng.integers(-rate // 2 + 1, rate // 2, size=N)
+        if it % 3 == 2:
+            nfft = int(rng.choice([16, 50, 250, 1000]))
+            L = int(nfft * rng.integers(F + 2, 60) + rng.integers(0, nfft))
+            mk = lambda: make_pfb(freq, rate, nfft, F, L)
+        else:
+            M = int(rng.choice([4, 10, 32, 100, 250, 1000]))
+            L = int(M * rng.integers(max(F, 4), 400))
+            mk = lambda: make_direct(freq, rate, M, F, L)
+        a, b = mk(), mk()
+        ran_mfma += b.kernel_name.startswith("ddc_mfma")
+        xs = [torch.from_numpy((crandn(rng, L) * np.float32(10.0 ** rng.integers(-3, 3))).astype(np.complex64))
+              .to(cuda_device) for _ in range(7)]
+        out_a = torch.empty(a.out_capacity, dtype=torch.complex64, device=cuda_device)
+        outs = [torch.zeros(b.out_capacity, dtype=torch.complex64, device=cuda_device) for _ in xs]
+        want = []
+        for x in xs:
+            n = a.process_device(x, out_a)
+            torch.cuda.synchronize()
+            want.append(out_a[:n].cpu().numpy())
+        got, pending = [], []
+        for k, x in enumerate(xs):
+            if len(pending) == 4:
+                j = pending.pop(0)
+                got.append(outs[j][:b.wait()].cpu().numpy())
+            b.submit_device(x, outs[k])
+            pending.append(k)
+        while pending:
+            j = pending.pop(0)
+            got.append(outs[j][:b.wait()].cpu().numpy())
+        for k, (y, yr) in enumerate(zip(got, want)):
+            np.testing.assert_array_equal(y, yr, err_msg="shape %d (%s N=%d F=%d L=%d) buffer %d"
+                                          % (it, b.kernel_name, N, F, L, k))
+        a.close()
+        b.close()
+    assert ran_mfma >= 18
+
+
 def test_profile_sampling(cuda_device, gsdr_lib):
     """gsdr_demod_profile_enable(n): hipEvents around every n-th launch of the dominant kernel."""
     import torch
