@@ -98,6 +98,17 @@ __device__ __forceinline__ unsigned lane_xor(unsigned v, int d) {
     return (unsigned)__builtin_amdgcn_ds_bpermute((lane ^ d) << 2, (int)v);
 }
 
+// Timing-only builds (WRONG results: no stores / one block only) exist for the ablation tables of
+// DESIGN.md only.  They are compiled in by -DGSDR_TIMING_BUILD (scratch/ablate*.sh); the shipped
+// library has no such path: the two predicates fold to false.
+#ifdef GSDR_TIMING_BUILD
+__device__ __forceinline__ bool timing_no_stores(const MfmaShape &sh) { return (sh.timing_mode & 1) != 0; }
+__device__ __forceinline__ bool timing_one_block(const MfmaShape &sh) { return (sh.timing_mode & 2) != 0; }
+#else
+__device__ __forceinline__ bool timing_no_stores(const MfmaShape &) { return false; }
+__device__ __forceinline__ bool timing_one_block(const MfmaShape &) { return false; }
+#endif
+
 // max |component| over this and the previous buffer: absmax_kernel keeps 16 partial
 // maxima per slot (float bits of non-negative numbers order like unsigned integers)
 __device__ __forceinline__ unsigned slot_max(const unsigned *slots, int cur, int prev) {
@@ -431,7 +442,7 @@ __device__ __forceinline__ __attribute__((target("no-packed-fp32-ops"))) void ri
     constexpr int KS = 4;
     const MfmaShape &sh = a.sh;
     const int Np = sh.NT32 * 32;
-    const int nhi = (sh.timing_mode & 2) ? 1 : (sh.nk8 + KS - 1) / KS;
+    const int nhi = timing_one_block(sh) ? 1 : (sh.nk8 + KS - 1) / KS;
     // Everything per lane is derived again for every tile, from an id the compiler cannot see
     // through: it has twelve registers of its own across the assembly (v0..v11), and what it
     // would carry over from the first tile it would have to park in AGPRs.
@@ -483,7 +494,7 @@ __device__ __forceinline__ __attribute__((target("no-packed-fp32-ops"))) void ri
                    [first] "s"(__builtin_amdgcn_readfirstlane(first)),
                    [scale] "v"(S)
                  : GSDR_MFMA_RING_CLOBBERS);
-    if (active && !(sh.timing_mode & 1)) {
+    if (active && !timing_no_stores(sh)) {
         unsigned tid2 = threadIdx.x;
         asm volatile("" : "+v"(tid2));
         const int lane2 = (int)(tid2 & 63u);
@@ -558,7 +569,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
     const int tg_raw = (q % sh.ntq) * W + wave;
     const bool active = tg_raw < sh.ntg;
     const int tg = active ? tg_raw : sh.ntg - 1;
-    const int nhi = (sh.timing_mode & 2) ? 1 : (sh.nk8 + KS - 1) / KS;
+    const int nhi = timing_one_block(sh) ? 1 : (sh.nk8 + KS - 1) / KS;
     const int L = (int)sh.nx, cl = sh.carry_len;
 
     if (gt == sh.ngt - 1 && q % sh.ntq == 0) {
@@ -643,7 +654,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
                    [nhi] "s"(__builtin_amdgcn_readfirstlane(nhi)),
                    [scale] "v"(S)
                  : GSDR_MFMA_RINGD_CLOBBERS);
-    if (!active || (sh.timing_mode & 1)) return;
+    if (!active || timing_no_stores(sh)) return;
     float16v accr[1], acci[1];
     const float4v *acc = reinterpret_cast<const float4v *>(lds) + wave * 512 + lane;
 #pragma unroll

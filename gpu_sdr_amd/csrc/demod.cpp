@@ -18,8 +18,12 @@
 #include <utility>
 #include <vector>
 
+#include <unistd.h>
+
 #include "../../include/gsdr.h"
 #include "ddc_kernels.h"
+
+extern char **environ;
 
 using gsdr::ChirpShape;
 using gsdr::DdcLaunch;
@@ -414,7 +418,11 @@ int setup_mfma(gsdr_demod *h, bool direct, const std::vector<long long> &tone) {
     sh.inv_rate = 1.0 / (double)rate;
     sh.m_mod_rate = (unsigned)M % rate;
     sh.unscale = unscale;
-    sh.timing_mode = env_int("GSDR_MFMA_TIMING", 0);
+#ifdef GSDR_TIMING_BUILD
+    sh.timing_mode = env_int("GSDR_MFMA_TIMING", 0);   // ablation builds only (scratch/), never shipped
+#else
+    sh.timing_mode = 0;
+#endif
     sh.rt = env_int("GSDR_MFMA_RT", 0);   // 0: chosen per launch in enqueue_mfma
     if (sh.rt < 0 || sh.rt > 2) sh.rt = 0;
     if (direct) {
@@ -1292,6 +1300,51 @@ int gsdr_demod_profile_read(gsdr_demod *h, double *total_ms) {
 }
 
 const char *gsdr_demod_kernel_name(const gsdr_demod *h) { return h ? h->kernel_name : "none"; }
+
+const char *gsdr_build_info(void) {
+#ifdef GSDR_TIMING_BUILD
+    return "abi 1; arch gfx950; timing_build 1";
+#else
+    return "abi 1; arch gfx950; timing_build 0";
+#endif
+}
+
+int gsdr_demod_describe(const gsdr_demod *h, char *buf, int cap) {
+    if (!h || !buf || cap < 1) return 0;
+    static const char *modes[] = {"TONES", "CHIRP", "NOISE", "RAMP", "NODSP", "SWONLY", "DIRECT"};
+    std::string s = "{\"mode\": \"";
+    s += (h->mode >= 0 && h->mode <= 6) ? modes[h->mode] : "?";
+    s += "\", \"kernel\": \"";
+    s += h->kernel_name;
+    s += "\", \"family\": \"";
+    s += h->mfma ? "f16 MFMA, hi/lo split" : (h->mode == GSDR_CHIRP ? "fp32 VALU, integer phase" : (h->pipe ? "packed fp32 VALU" : "fp32 VALU"));
+    s += "\", \"channels\": " + std::to_string(h->ddc_channels > 0 ? h->ddc_channels : h->N);
+    s += ", \"row_tiles_per_workgroup\": " + std::to_string(h->mfma ? (h->mf.rt > 0 ? h->mf.rt : 0) : 0);
+    s += ", \"pipeline_streams\": " + std::to_string(h->s_up ? h->pipe_streams : env_int("GSDR_PIPE_STREAMS", kPipeStreams));
+    s += ", \"timing_build\": ";
+#ifdef GSDR_TIMING_BUILD
+    s += "1";
+#else
+    s += "0";
+#endif
+    s += ", \"env\": {";
+    bool first = true;
+    for (char **e = environ; e && *e; ++e) {
+        if (std::strncmp(*e, "GSDR_", 5) != 0) continue;
+        const char *eq = std::strchr(*e, '=');
+        if (!eq) continue;
+        std::string k(*e, eq - *e), v(eq + 1);
+        for (auto &c : v)
+            if (c == '"' || c == '\\' || (unsigned char)c < 0x20) c = '?';
+        s += (first ? "\"" : ", \"") + k + "\": \"" + v + "\"";
+        first = false;
+    }
+    s += "}}";
+    const int n = (int)s.size() < cap - 1 ? (int)s.size() : cap - 1;
+    std::memcpy(buf, s.data(), (size_t)n);
+    buf[n] = 0;
+    return n;
+}
 
 // ---- synthetic sources -----------------------------------------------------
 int gsdr_source_tones(gsdr_c64 *out_dev, long long n, long long start, int rate, const int *freq,

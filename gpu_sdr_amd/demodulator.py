@@ -166,6 +166,14 @@ class RX_buffer_demodulator:
     def kernel_name(self) -> str:
         return self._L.gsdr_demod_kernel_name(self._h).decode()
 
+    def describe(self) -> dict:
+        """The engine this handle resolved to (gsdr_demod_describe): dominant kernel, family,
+        row tiles per workgroup, pipeline streams, every GSDR_* variable set in the process."""
+        import json
+        buf = C.create_string_buffer(4096)
+        self._L.gsdr_demod_describe(self._h, buf, len(buf))
+        return json.loads(buf.value.decode())
+
     def window(self) -> np.ndarray:
         n = self._L.gsdr_demod_get_window(self._h, None, 0)
         w = np.empty(n, dtype=np.float32)

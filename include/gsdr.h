@@ -116,6 +116,16 @@ const char *gsdr_last_error(const gsdr_demod *h);
 
 /* ---- introspection ------------------------------------------------------ */
 int gsdr_abi_version(void);
+/* "abi 1; arch gfx950; timing_build 0".  timing_build 1 marks an ablation build
+ * (-DGSDR_TIMING_BUILD, scratch/ only) whose kernels can be told to skip work;
+ * the shipped library is always 0 and bench.py refuses anything else. */
+const char *gsdr_build_info(void);
+/* One-line JSON object describing the engine this handle resolved to: mode,
+ * dominant kernel, kernel family, row tiles per workgroup, pipeline streams,
+ * and every GSDR_* environment variable that was set in the process (the
+ * tuning knobs are read at create time).  Returns the text length (truncated
+ * to cap-1 characters + NUL). */
+int gsdr_demod_describe(const gsdr_demod *h, char *buf, int cap);
 /* gsdr_w_type actually dispatched (ref: USRP_demodulator.cpp:19-25,56). */
 int gsdr_demod_mode(const gsdr_demod *h);
 /* parameters->wave_type.size(), what rx_single_link stores in
