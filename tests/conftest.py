@@ -36,3 +36,14 @@ def cuda_device():
     if not torch.cuda.is_available():
         pytest.fail("GPU test selected but no GPU is visible (no CPU fallback exists)")
     return torch.device("cuda:0")
+
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+if HERE not in sys.path:
+    sys.path.insert(0, HERE)
+
+from _margins import MARGINS, record_margin, write_margins  # noqa: E402,F401
+
+
+def pytest_sessionfinish(session, exitstatus):
+    write_margins(exitstatus)

@@ -67,3 +67,134 @@ def test_workload_table_matches_baseline_json():
     assert abs(b - 28.48) < 1e-9 and f == 5632
     b, f = bench.algorithmic(bench.WORKLOADS["c3"], 2048)
     assert abs(b - 24.384) < 1e-9 and f == 45056
+
+
+# ---------------------------------------------------------------------------
+# bench.main() end to end on CPU: spawn -> time_workload (barrier, repeats agreed over the
+# ranks, max-over-ranks) -> ONE line from rank 0 whose value is the aggregate of all ranks.
+# The demodulator is a stub that sleeps (no GPU here); everything else is bench.py's own code.
+# ---------------------------------------------------------------------------
+class _StubDemod:
+    kernel_name = "stub_kernel"
+
+    def __init__(self, step_s):
+        self.step_s, self.pending, self.calls = step_s, 0, 0
+
+    def process_device(self, buf, out, stream):
+        import time
+        time.sleep(self.step_s)
+        self.calls += 1
+        return 1
+
+    def submit_device(self, buf, out):
+        import time
+        time.sleep(self.step_s)
+        self.calls += 1
+        self.pending += 1
+
+    def wait(self):
+        assert self.pending > 0
+        self.pending -= 1
+        return 1
+
+    def profile_enable(self, every):
+        self.every = every
+
+    def profile_read(self):
+        return self.calls // max(self.every, 1), 1e3 * self.step_s * (self.calls // max(self.every, 1))
+
+    def describe(self):
+        return {"kernel": self.kernel_name, "env": {}}
+
+    def close(self):
+        assert self.pending == 0
+
+
+class _StubEngine:
+    """rank r's steps take (1 + r) ms: the slower rank sets the time of the job"""
+
+    def __init__(self, rank):
+        self.rank = rank
+
+    def sync(self, device):
+        pass
+
+    def stream(self, device):
+        return None
+
+    def build(self, wl, device, seed, ring=8, n_tones=None):
+        import bench
+        assert seed == bench.stream_seed(self.rank)
+        return _StubDemod(1e-3 * (1 + self.rank)), [None] * ring, [None] * bench.PIPE_DEPTH, n_tones or wl.get("n_tones", 1)
+
+
+def _bench_worker(rank, world, port, q):
+    import contextlib
+    import io
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GSDR_BENCH_BACKEND="gloo")
+    import bench
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        line = bench.main(["--gpus", str(world), "--steps", "20", "--warmup", "2", "--min-seconds", "0.2",
+                           "--workload", "c3"], engine=_StubEngine(rank))
+    q.put((rank, buf.getvalue(), line))
+
+
+def test_bench_main_two_ranks_stub_engine():
+    import json
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    out0, out1 = res[0][1].strip(), res[1][1].strip()
+    assert out1 == ""                                   # only rank 0 prints
+    assert len(out0.splitlines()) == 1                  # ... ONE line
+    line = json.loads(out0)
+    assert line["n_gpus"] == 2 and line["steps"] == 20 and line["warmup"] == 2
+    assert line["config"]["key"] == "c3" and line["config"]["streams"] == 2
+    assert line["config"]["control_plane"] == "gloo"
+    assert line["scaling"] == "weak" and line["vs_baseline"] is None
+    # both ranks agreed on the same repeat count (MAX of the per-rank estimates -> from the slow rank)
+    assert res[0][2]["repeats"] == res[1][2]["repeats"] >= 1
+    R = line["repeats"]
+    assert line["timed_region_s"] >= 0.2 * 0.8
+    # the slow rank (2 ms per step) sets the elapsed time; value = samples of BOTH ranks / that
+    ms = line["ms_per_step"]
+    assert 1.9 <= ms <= 4.0, ms
+    want = 2 * 20 * R * 1_000_000 / (ms * 1e-3 * 20 * R) / 1e6
+    assert abs(line["value"] - want) / want < 1e-3
+    assert line["roofline"] is not None and line["roofline"]["kernel"] == "stub_kernel"
+
+
+def test_bench_refuses_timing_switches():
+    import subprocess
+    env = dict(os.environ, GSDR_MFMA_TIMING="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu", "--no-extras"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 2 and "refusing" in p.stderr
+    env = dict(os.environ, GSDR_LIB="/tmp/some_ablation_build.so")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu", "--no-extras"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 2 and "refusing" in p.stderr
+
+
+def test_backend_choice():
+    sys.path.insert(0, ROOT)
+    import bench
+    old = os.environ.pop("GSDR_BENCH_BACKEND", None)
+    try:
+        assert bench.pick_backend(8, 8) == "nccl"      # one GPU per rank: RCCL
+        assert bench.pick_backend(2, 1) == "gloo"      # ranks share a device: RCCL would refuse ("Duplicate GPU")
+        assert bench.pick_backend(1, 1) == "nccl"
+    finally:
+        if old is not None:
+            os.environ["GSDR_BENCH_BACKEND"] = old
