@@ -81,6 +81,7 @@ SIGNATURES = [
     ("gsdr_demod_submit", C.c_int, [_vp, _vp, _vp]),
     ("gsdr_demod_submit_device", C.c_int, [_vp, _vp, _vp]),
     ("gsdr_demod_wait", C.c_int, [_vp]),
+    ("gsdr_demod_prepare", C.c_int, [_vp, C.c_int]),
     ("gsdr_demod_close", None, [_vp]),
     ("gsdr_last_error", C.c_char_p, [_vp]),
     ("gsdr_abi_version", C.c_int, []),

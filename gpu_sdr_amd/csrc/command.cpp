@@ -8,6 +8,8 @@
 // cpp/USRP_server_network.cpp:497-501, Sync_server::format_net_buffer :164-191,
 // string_to_w_type / ant_mode_from_string cpp/USRP_server_settings.cpp.
 // (citations relative to /root/reference)
+#include <cctype>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -106,12 +108,16 @@ struct JParser {
         if (end - p >= 4 && !std::strncmp(p, "true", 4)) { v.kind = JValue::Bool; v.b = true; p += 4; return true; }
         if (end - p >= 5 && !std::strncmp(p, "false", 5)) { v.kind = JValue::Bool; v.b = false; p += 5; return true; }
         if (end - p >= 4 && !std::strncmp(p, "null", 4)) { v.kind = JValue::Null; p += 4; return true; }
+        // a JSON number: plain decimal text only (strtod alone would also take nan, inf and hex)
+        const char *t = p;
+        while (t < end && t - p < 64 && (std::isdigit((unsigned char)*t) || *t == '-' || *t == '+' || *t == '.' || *t == 'e' || *t == 'E')) ++t;
+        if (t == p) return fail("unexpected character");
         char *q = nullptr;
-        std::string tmp(p, (size_t)((end - p) < 64 ? (end - p) : 64));
+        std::string tmp(p, (size_t)(t - p));
         v.num = std::strtod(tmp.c_str(), &q);
-        if (q == tmp.c_str()) return fail("unexpected character");
+        if (q != tmp.c_str() + tmp.size() || !std::isfinite(v.num)) return fail("malformed number");
         v.kind = JValue::Num;
-        p += (q - tmp.c_str());
+        p = t;
         return true;
     }
 };
@@ -123,16 +129,33 @@ bool as_double(const JValue *v, double &out) {
     if (v->kind == JValue::Num) { out = v->num; return true; }
     if (v->kind == JValue::Bool) { out = v->b ? 1 : 0; return true; }
     if (v->kind == JValue::Str) {
+        // numeric text: plain decimal only, finite (a stream extraction refuses nan/inf/hex too)
+        if (v->str.empty() || v->str.size() > 64) return false;
+        for (char ch : v->str)
+            if (!(std::isdigit((unsigned char)ch) || ch == '-' || ch == '+' || ch == '.' || ch == 'e' || ch == 'E')) return false;
         char *q = nullptr;
         out = std::strtod(v->str.c_str(), &q);
-        return q != v->str.c_str() && *q == 0;
+        return q != v->str.c_str() && *q == 0 && std::isfinite(out);
     }
     return false;
 }
 bool as_integer(const JValue *v, long long &out) {  // get<int>/get<size_t>: text must be an integer
     double d;
-    if (!as_double(v, d) || d != std::floor(d) || std::fabs(d) > 9.2e18) return false;
+    if (!as_double(v, d) || d != std::floor(d) || std::fabs(d) > 9.0e18) return false;
     out = (long long)d;
+    return true;
+}
+// The reference reads most scalars with get<double> and lets C++ narrow them (undefined for
+// values the target cannot hold).  Here a value outside the target's range is a type error:
+// int fields within (INT_MIN, INT_MAX], size_t fields within [0, 2^53].
+bool to_int(double d, int &out) {
+    if (!(d > (double)INT_MIN && d <= (double)INT_MAX)) return false;
+    out = (int)d;
+    return true;
+}
+bool to_size(double d, unsigned long long &out) {
+    if (!(d >= 0.0 && d <= 9007199254740992.0)) return false;
+    out = (unsigned long long)d;
     return true;
 }
 
@@ -198,22 +221,23 @@ bool fill(const JValue &root, gsdr_command &c) {
     EACH({ const JValue *v = J.get("mode"); if (!v || v->kind != JValue::Str) return type_error("mode");
            A.mode = ant_mode_from_string(v->str); })
     double d; long long n;
-    EACH({ if (!as_double(J.get("rf"), d)) return type_error("rf"); A.tone = (unsigned long long)d; })
-    EACH({ if (!as_integer(J.get("tuning_mode"), n) || n < 0) return type_error("tuning_mode"); A.tuning_mode = (int)n; })
-    EACH({ if (!as_double(J.get("rate"), d)) return type_error("rate"); A.rate = (int)d; })
-    EACH({ if (!as_double(J.get("decim"), d)) return type_error("decim"); A.decim = (unsigned long long)d; })
-    EACH({ if (!as_double(J.get("fft_tones"), d)) return type_error("fft_tones"); A.fft_tones = (int)d; })
-    EACH({ if (!as_double(J.get("pf_average"), d)) return type_error("pf_average"); A.pf_average = (unsigned long long)d; })
+    EACH({ if (!as_double(J.get("rf"), d) || !to_size(d, A.tone)) return type_error("rf"); })
+    EACH({ if (!as_integer(J.get("tuning_mode"), n) || n < 0 || n > INT_MAX) return type_error("tuning_mode"); A.tuning_mode = (int)n; })
+    EACH({ if (!as_double(J.get("rate"), d) || !to_int(d, A.rate)) return type_error("rate"); })
+    EACH({ if (!as_double(J.get("decim"), d) || !to_size(d, A.decim)) return type_error("decim"); })
+    EACH({ if (!as_double(J.get("fft_tones"), d) || !to_int(d, A.fft_tones)) return type_error("fft_tones"); })
+    EACH({ if (!as_double(J.get("pf_average"), d) || !to_size(d, A.pf_average)) return type_error("pf_average"); })
     EACH({ if (!as_integer(J.get("samples"), n) || n < 0) return type_error("samples"); A.samples = (unsigned long long)n; })
-    EACH({ if (!as_double(J.get("buffer_len"), d)) return type_error("buffer_len"); A.buffer_len = (unsigned long long)d; })
+    EACH({ if (!as_double(J.get("buffer_len"), d) || !to_size(d, A.buffer_len)) return type_error("buffer_len"); })
     EACH({ if (!as_double(J.get("burst_off"), d)) return type_error("burst_off"); A.burst_off = (float)d; })
     EACH({ if (!as_double(J.get("burst_on"), d)) return type_error("burst_on"); A.burst_on = (float)d; })
-    EACH({ if (!as_double(J.get("bw"), d)) return type_error("bw"); A.bw = (int)d; })
+    EACH({ if (!as_double(J.get("bw"), d) || !to_int(d, A.bw)) return type_error("bw"); })
     EACH({ if (!as_double(J.get("delay"), d)) return type_error("delay"); A.delay = d; })
-    EACH({ if (!as_double(J.get("gain"), d)) return type_error("gain"); A.gain = (int)d; })
+    EACH({ if (!as_double(J.get("gain"), d) || !to_int(d, A.gain)) return type_error("gain"); })
 #define INT_LIST(key, field)                                                                     \
     EACH({ const JValue *v = J.get(key); if (!v || v->kind != JValue::Arr) return type_error(key); \
-           for (auto &e : v->arr) { if (!as_integer(&e, n)) return type_error(key); A.field.push_back((int)n); } })
+           for (auto &e : v->arr) { if (!as_integer(&e, n) || n <= (long long)INT_MIN || n > (long long)INT_MAX) return type_error(key);  \
+                                    A.field.push_back((int)n); } })
 #define FLT_LIST(key, field)                                                                     \
     EACH({ const JValue *v = J.get(key); if (!v || v->kind != JValue::Arr) return type_error(key); \
            for (auto &e : v->arr) { if (!as_double(&e, d)) return type_error(key); A.field.push_back((float)d); } })
@@ -225,7 +249,7 @@ bool fill(const JValue &root, gsdr_command &c) {
     FLT_LIST("chirp_t", chirp_t)
     INT_LIST("chirp_f", chirp_f)
     INT_LIST("swipe_s", swipe_s)
-    EACH({ if (!as_double(J.get("data_mem_mult"), d)) return type_error("data_mem_mult"); A.data_mem_mult = (unsigned long long)d; })
+    EACH({ if (!as_double(J.get("data_mem_mult"), d) || !to_size(d, A.data_mem_mult)) return type_error("data_mem_mult"); })
 #undef EACH
 #undef INT_LIST
 #undef FLT_LIST
@@ -242,6 +266,17 @@ bool check(gsdr_command &c) {
         if (pfb) {
             if (A.pf_average <= 0) A.pf_average = 1;
             if (A.fft_tones <= 0) A.fft_tones = 2;
+        }
+        if (A.mode == 0) {
+            // a TX tone comb reads ampl[k] and freq[k] for every wave_type entry (ref: tone_gen,
+            // cpp/kernels.cu:589-684, buffer_generator.cpp:60-157): short lists would be read past
+            size_t tones = 0;
+            for (int w : A.wave_type) tones += (w == GSDR_TONES);
+            if (tones > 0 && (A.ampl.size() < A.wave_type.size() || A.freq.size() < A.wave_type.size())) {
+                g_cmd_error = std::string("Number of amplitude/frequency descriptors does not match the number of "
+                                          "signal mode descriptor in parameter '") + kAnt[i] + "'";
+                return false;
+            }
         }
         if (A.buffer_len == 0) A.buffer_len = 1000000;                         // DEFAULT_BUFFER_LEN
         if (A.buffer_len > 6000000 || A.buffer_len < 50000) A.buffer_len = 1000000;  // MAX/MIN_USEFULL_BUFFER

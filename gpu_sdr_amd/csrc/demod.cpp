@@ -71,6 +71,7 @@ struct gsdr_demod {
         int n = 0;
     } slot[GSDR_PIPELINE_DEPTH];
     hipStream_t s_up = nullptr, s_down = nullptr;
+    bool pipe_ready = false;             // pipeline_init() succeeded
     int pipe_head = 0, pipe_count = 0;   // oldest outstanding slot, number outstanding
 
     // ---- DDC (DIRECT / TONES) ----
@@ -102,6 +103,7 @@ struct gsdr_demod {
     int mf_TT = 1, mf_PK = 32, mf_W = 4;   // tone tiles per wave, phasor block, waves per workgroup
     gsdr::MfmaKernel mf_kind = gsdr::MfmaKernel::AsmRing;
     gsdr::MfmaShape mf{};              // fields that do not change between calls
+    int last_rt = 0;                   // row tiles per workgroup of the last launch (describe())
     uint4 *d_bfrag = nullptr;
     float2 *d_ptab = nullptr, *d_dtab = nullptr;
     float *d_mtaps = nullptr;
@@ -116,6 +118,12 @@ struct gsdr_demod {
     hipStream_t s_main[kPipeStreams] = {};
     int pipe_streams = kPipeStreams;   // how many of them are used (GSDR_PIPE_STREAMS)
     hipEvent_t ev_abs[4] = {nullptr, nullptr, nullptr, nullptr};    // staging pass of call j done
+    // Streams that carry work of this handle nobody has been ordered behind yet.  The carry, the
+    // scale slots, the raw windows and the head/tail copies pass from one call to the next ON THE
+    // DEVICE: a call that runs on another stream than its predecessors first joins them (an event
+    // recorded on the old stream at that moment covers everything enqueued there before).
+    std::vector<hipStream_t> dirty;
+    hipEvent_t ev_join = nullptr;
     bool pipe_overlap = false;         // set around the compute of an overlapped call
     unsigned long long pipe_seq = 0;   // overlapped calls so far
     unsigned long long call_no = 0;    // absmax slot rotation
@@ -450,6 +458,27 @@ int enqueue_mfma(gsdr_demod *h, const float2 *in, float2 *raw, long long raw_new
                  int nout, unsigned idx_base, float2 *out, hipStream_t st, const float2 *spare_src = nullptr,
                  long long spare_n = 0);
 
+// Orders `st` behind every stream in h->dirty for which keep(s) is false, and forgets those.
+template <typename Keep>
+int join_streams(gsdr_demod *h, hipStream_t st, Keep keep) {
+    size_t w = 0;
+    for (size_t i = 0; i < h->dirty.size(); ++i) {
+        hipStream_t s = h->dirty[i];
+        if (s == st || keep(s)) {
+            h->dirty[w++] = s;
+            continue;
+        }
+        if (!h->ev_join) HIPCHK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+        HIPCHK(h, hipEventRecord(h->ev_join, s));
+        HIPCHK(h, hipStreamWaitEvent(st, h->ev_join, 0));
+    }
+    h->dirty.resize(w);
+    bool have = false;
+    for (hipStream_t s : h->dirty) have |= (s == st);
+    if (!have) h->dirty.push_back(st);
+    return 0;
+}
+
 int record_begin(gsdr_demod *h, hipStream_t st, hipEvent_t *stop) {
     *stop = nullptr;
     if (!h->prof || h->ev_used >= (size_t)kMaxEvents) return 0;
@@ -578,6 +607,7 @@ int enqueue_mfma(gsdr_demod *h, const float2 *in, float2 *raw, long long raw_new
         const long long wgs = (long long)a.sh.ngt * a.sh.ntq;
         a.sh.rt = h->pipe_overlap && nblk <= 32 && wgs >= 512 && wgs < 1024 ? 2 : 1;
     }
+    h->last_rt = a.sh.rt;
     if (raw) {
         // TONES: one pass brings the carried samples to the front of this call's raw window,
         // appends the buffer and takes its maximum; every row reads the window itself
@@ -1031,6 +1061,13 @@ int gsdr_demod_process_device(gsdr_demod *h, const gsdr_c64 *in_dev, gsdr_c64 *o
     }
     if (h->device >= 0) HIPCHK(h, hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)hip_stream;  // NULL is HIP's null stream, as everywhere in HIP
+    // An in-order call is a join point: it runs behind everything this handle has in flight on
+    // other streams (an earlier call on another stream, overlapped calls still running).  Free on
+    // the usual path (same stream as the call before).  Overlapped calls order themselves among
+    // their compute streams (pipeline_compute) and only join the in-order streams.
+    if (!h->pipe_overlap) {
+        if (join_streams(h, st, [](hipStream_t) { return false; })) return -1;
+    }
     const float2 *in = reinterpret_cast<const float2 *>(in_dev);
     float2 *out = reinterpret_cast<float2 *>(out_dev);
     switch (h->mode) {
@@ -1073,9 +1110,43 @@ int gsdr_demod_process(gsdr_demod *h, const gsdr_c64 *in_host, gsdr_c64 *out_hos
     return ret;
 }
 
-// streams and events of the pipelined entries, created on first use
+static void pipeline_teardown(gsdr_demod *h) {
+    for (auto &sl : h->slot) {
+        if (sl.up) (void)hipEventDestroy(sl.up);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+        if (sl.down) (void)hipEventDestroy(sl.down);
+        sl.up = sl.done = sl.down = sl.wait_ev = nullptr;
+    }
+    for (int i = 0; i < kPipeStreams; ++i) {
+        if (h->s_main[i]) (void)hipStreamDestroy(h->s_main[i]);
+        h->s_main[i] = nullptr;
+    }
+    for (int i = 0; i < 4; ++i) {
+        if (h->ev_abs[i]) (void)hipEventDestroy(h->ev_abs[i]);
+        h->ev_abs[i] = nullptr;
+    }
+    if (h->s_up) (void)hipStreamDestroy(h->s_up);
+    if (h->s_down) (void)hipStreamDestroy(h->s_down);
+    h->s_up = h->s_down = nullptr;
+}
+
+static int pipeline_init_parts(gsdr_demod *h);
+
+// streams and events of the pipelined entries, created on first use; all or nothing: a partial
+// failure leaves no half-built pipeline behind for the next call to trip over
 static int pipeline_init(gsdr_demod *h) {
-    if (h->s_up) return 0;
+    if (h->pipe_ready) return 0;
+    if (pipeline_init_parts(h)) {
+        const std::string keep = h->err;
+        pipeline_teardown(h);
+        h->err = keep;
+        return -1;
+    }
+    h->pipe_ready = true;
+    return 0;
+}
+
+static int pipeline_init_parts(gsdr_demod *h) {
     HIPCHK(h, hipStreamCreateWithFlags(&h->s_up, hipStreamNonBlocking));
     HIPCHK(h, hipStreamCreateWithFlags(&h->s_down, hipStreamNonBlocking));
     for (auto &sl : h->slot) {
@@ -1135,6 +1206,16 @@ static int pipeline_compute(gsdr_demod *h, gsdr_demod::Slot &sl, hipEvent_t up, 
     const bool overlap = env_int("GSDR_PIPE_OVERLAP", 1) != 0 && h->mfma && ddc;
     hipStream_t cs = overlap ? h->s_main[h->pipe_seq % (unsigned)h->pipe_streams] : h->stream;
     if (up) HIPCHK(h, hipStreamWaitEvent(cs, up, 0));
+    if (overlap) {
+        // behind in-order calls made on other streams since (their carry, slot and window writes);
+        // the compute streams of the pipeline are ordered by the protocol above
+        if (join_streams(h, cs, [h](hipStream_t s) {
+                for (int i = 0; i < kPipeStreams; ++i)
+                    if (s == h->s_main[i]) return true;
+                return false;
+            }))
+            return -1;
+    }
     if (overlap && h->pipe_seq > 0) HIPCHK(h, hipStreamWaitEvent(cs, h->ev_abs[(h->pipe_seq - 1) % 4], 0));
     h->pipe_overlap = overlap;
     const int n = gsdr_demod_process_device(h, reinterpret_cast<const gsdr_c64 *>(in),
@@ -1144,6 +1225,28 @@ static int pipeline_compute(gsdr_demod *h, gsdr_demod::Slot &sl, hipEvent_t up, 
     if (n < 0) return -1;
     HIPCHK(h, hipEventRecord(sl.done, cs));
     return n;
+}
+
+int gsdr_demod_prepare(gsdr_demod *h, int what) {
+    if (!h) return -1;
+    if (h->device >= 0) HIPCHK(h, hipSetDevice(h->device));
+    if (h->mode == GSDR_NODSP) return 0;
+    if ((what & GSDR_PREPARE_HOST) && !h->d_in) {
+        HIPCHK(h, dev_alloc(&h->d_in, (size_t)h->L));
+        HIPCHK(h, dev_alloc(&h->d_out, (size_t)h->capacity));
+    }
+    if (what & (GSDR_PREPARE_PIPELINE | GSDR_PREPARE_PIPELINE_HOST)) {
+        if (pipeline_init(h)) return -1;
+    }
+    if (what & GSDR_PREPARE_PIPELINE_HOST) {
+        for (auto &sl : h->slot)
+            if (!sl.d_in) {
+                HIPCHK(h, dev_alloc(&sl.d_in, (size_t)h->L));
+                HIPCHK(h, dev_alloc(&sl.d_out, (size_t)h->capacity));
+            }
+    }
+    HIPCHK(h, hipDeviceSynchronize());
+    return 0;
 }
 
 int gsdr_demod_submit(gsdr_demod *h, const gsdr_c64 *in_host, gsdr_c64 *out_host) {
@@ -1205,9 +1308,14 @@ int gsdr_demod_wait(gsdr_demod *h) {
     if (h->pipe_count == 0) return -2;
     if (h->device >= 0) HIPCHK(h, hipSetDevice(h->device));
     auto &sl = h->slot[h->pipe_head];
-    HIPCHK(h, hipEventSynchronize(sl.wait_ev));
+    const hipError_t e = hipEventSynchronize(sl.wait_ev);
+    // the slot leaves the queue whatever happened: a failed wait must not leave the pipeline "full"
     h->pipe_head = (h->pipe_head + 1) % GSDR_PIPELINE_DEPTH;
     h->pipe_count--;
+    if (e != hipSuccess) {
+        h->err = std::string("hipEventSynchronize: ") + hipGetErrorString(e);
+        return -1;
+    }
     return sl.n;
 }
 
@@ -1222,16 +1330,9 @@ void gsdr_demod_close(gsdr_demod *h) {
     for (auto &sl : h->slot) {
         if (sl.d_in) (void)hipFree(sl.d_in);
         if (sl.d_out) (void)hipFree(sl.d_out);
-        if (sl.up) (void)hipEventDestroy(sl.up);
-        if (sl.done) (void)hipEventDestroy(sl.done);
-        if (sl.down) (void)hipEventDestroy(sl.down);
     }
-    for (int i = 0; i < kPipeStreams; ++i)
-        if (h->s_main[i]) (void)hipStreamDestroy(h->s_main[i]);
-    for (int i = 0; i < 4; ++i)
-        if (h->ev_abs[i]) (void)hipEventDestroy(h->ev_abs[i]);
-    if (h->s_up) (void)hipStreamDestroy(h->s_up);
-    if (h->s_down) (void)hipStreamDestroy(h->s_down);
+    pipeline_teardown(h);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     for (auto &e : h->ev_pool) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
@@ -1319,8 +1420,8 @@ int gsdr_demod_describe(const gsdr_demod *h, char *buf, int cap) {
     s += "\", \"family\": \"";
     s += h->mfma ? "f16 MFMA, hi/lo split" : (h->mode == GSDR_CHIRP ? "fp32 VALU, integer phase" : (h->pipe ? "packed fp32 VALU" : "fp32 VALU"));
     s += "\", \"channels\": " + std::to_string(h->ddc_channels > 0 ? h->ddc_channels : h->N);
-    s += ", \"row_tiles_per_workgroup\": " + std::to_string(h->mfma ? (h->mf.rt > 0 ? h->mf.rt : 0) : 0);
-    s += ", \"pipeline_streams\": " + std::to_string(h->s_up ? h->pipe_streams : env_int("GSDR_PIPE_STREAMS", kPipeStreams));
+    s += ", \"row_tiles_per_workgroup\": " + std::to_string(h->mfma ? h->last_rt : 0);
+    s += ", \"pipeline_streams\": " + std::to_string(h->pipe_ready ? h->pipe_streams : env_int("GSDR_PIPE_STREAMS", kPipeStreams));
     s += ", \"timing_build\": ";
 #ifdef GSDR_TIMING_BUILD
     s += "1";

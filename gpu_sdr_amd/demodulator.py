@@ -166,6 +166,12 @@ class RX_buffer_demodulator:
     def kernel_name(self) -> str:
         return self._L.gsdr_demod_kernel_name(self._h).decode()
 
+    def prepare(self, host: bool = True, pipeline: bool = True, pipeline_host: bool = True) -> None:
+        """gsdr_demod_prepare: create now what the entries would create on first use."""
+        what = (1 if host else 0) | (2 if pipeline else 0) | (4 if pipeline_host else 0)
+        if self._L.gsdr_demod_prepare(self._h, what) != 0:
+            raise GsdrError(self._L.gsdr_last_error(self._h).decode())
+
     def describe(self) -> dict:
         """The engine this handle resolved to (gsdr_demod_describe): dominant kernel, family,
         row tiles per workgroup, pipeline streams, every GSDR_* variable set in the process."""

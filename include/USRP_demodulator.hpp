@@ -124,6 +124,10 @@ class RX_buffer_demodulator {
             std::exit(-1);
         }
         fcut = gsdr_demod_fcut(handle_);
+        // like the reference's constructor (ref: cpp/USRP_demodulator.cpp:59-119): every device
+        // buffer and stream exists before the first packet arrives
+        if (gsdr_demod_prepare(handle_, GSDR_PREPARE_HOST | GSDR_PREPARE_PIPELINE | GSDR_PREPARE_PIPELINE_HOST) != 0)
+            std::fprintf(stderr, "WARNING: demodulator: %s\n", gsdr_last_error(handle_));
         if (diagnostic_) std::fprintf(stderr, "WARNING: Demodulator diagnostic enabled.\n");
     }
 
@@ -169,9 +173,15 @@ class RX_buffer_demodulator {
         handle_ = nullptr;
     }
 
+    //! room *out must have (complex samples); the reference sizes its pool as
+    //! buffer_len * max(data_mem_mult, 1) (ref: cpp/USRP_server_link_threads.cpp:143-150)
+    long long out_capacity() const { return gsdr_demod_out_capacity(handle_); }
+
    private:
     gsdr_demod* handle_;
     bool diagnostic_;
 };
+
+inline long long gsdr_demod_out_capacity_of(const RX_buffer_demodulator* d) { return d->out_capacity(); }
 
 #endif

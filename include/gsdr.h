@@ -80,7 +80,11 @@ int gsdr_demod_process(gsdr_demod *h, const gsdr_c64 *in_host, gsdr_c64 *out_hos
  * synchronised: the caller orders it against the producer of in_dev and the
  * consumer of out_dev through that stream.
  * The returned length is known on the host before the kernels finish.  This
- * is the entry the synthetic in-HBM source and bench.py use. */
+ * is the entry the synthetic in-HBM source and bench.py use.
+ * Consecutive calls may use different streams, and may be mixed with the
+ * submit entries below: the state a call inherits (FIR carry, NCO index, raw
+ * windows) is ordered on the device -- a call on another stream than its
+ * predecessor first waits for it (one event; nothing on the usual path). */
 int gsdr_demod_process_device(gsdr_demod *h, const gsdr_c64 *in_dev,
                               gsdr_c64 *out_dev, void *hip_stream);
 
@@ -105,6 +109,17 @@ int gsdr_demod_wait(gsdr_demod *h);
  * three streams in turn: the next buffer starts on the compute units the last workgroups of this one
  * leave idle (GSDR_PIPE_OVERLAP=0: strictly one after the other). */
 int gsdr_demod_submit_device(gsdr_demod *h, const gsdr_c64 *in_dev, gsdr_c64 *out_dev);
+
+/* Creates now what the entries above would otherwise create on first use (device
+ * staging buffers of the host-pointer entries, the streams, events and per-slot
+ * buffers of the pipelined ones), so that the first buffers of a measurement are not
+ * late: the reference's constructor allocates everything up front as well (ref:
+ * cpp/USRP_demodulator.cpp:59-119), and include/USRP_demodulator.hpp calls this from
+ * its constructor.  `what` is a bit set; returns 0 or -1. */
+#define GSDR_PREPARE_HOST 1           /* gsdr_demod_process                  */
+#define GSDR_PREPARE_PIPELINE 2       /* gsdr_demod_submit_device / _wait    */
+#define GSDR_PREPARE_PIPELINE_HOST 4  /* gsdr_demod_submit / _wait           */
+int gsdr_demod_prepare(gsdr_demod *h, int what);
 
 /* ref: RX_buffer_demodulator::close, cpp/USRP_demodulator.cpp:333 (+ :466-698).
  * Frees every device allocation and the stream, then the handle itself. */

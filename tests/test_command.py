@@ -121,3 +121,61 @@ def test_replies_and_headers(gsdr_lib):
     rec = np.frombuffer(bytes(hdr21), dtype=header_type)[0]
     assert (rec["usrp_number"], rec["front_end_code"], rec["packet_number"], rec["length"], rec["errors"],
             rec["channels"]) == (3, b"B", 77, 2560000, 1, 256)
+
+
+def test_out_of_range_and_non_finite_values_are_nacked(gsdr_lib):
+    """The command socket is network facing: values the target type cannot hold are a type
+    error (the reference narrows a get<double>() with undefined behaviour there), text that is
+    not plain decimal is refused like boost's stream extraction refuses it."""
+    from tests.golden.make_commands import get_noise_direct
+
+    def cmd():
+        return get_noise_direct([1000, 2000], 1000000, 1, 10, 0)
+
+    def nacked(c, key, raw=None):
+        text = json.dumps(c) if raw is None else raw
+        h = parse(gsdr_lib, text)
+        if h:
+            gsdr_lib.gsdr_command_free(h)
+            return False
+        return key.encode() in gsdr_lib.gsdr_command_error()
+
+    for key, bad in [("decim", -1), ("decim", 1e300), ("rate", 1e300), ("rate", -3e9), ("fft_tones", 2.0 ** 40),
+                     ("pf_average", -4), ("buffer_len", -1), ("buffer_len", 1e30), ("bw", 1e12), ("gain", -1e12),
+                     ("data_mem_mult", -1), ("rf", -1.0), ("rf", 1e300), ("samples", -5), ("tuning_mode", 2 ** 40)]:
+        c = cmd()
+        c["A_RX2"][key] = bad
+        assert nacked(c, key), (key, bad)
+    # numeric text: nan / inf / hex are not numbers for a stream extraction
+    for key, bad in [("rate", "nan"), ("decim", "inf"), ("buffer_len", "0x10"), ("gain", "-inf"), ("delay", "NaN")]:
+        c = cmd()
+        c["A_RX2"][key] = bad
+        assert nacked(c, key), (key, bad)
+    # bare nan / Infinity tokens are not JSON at all
+    for tok in ("NaN", "Infinity", "-Infinity", "0x20"):
+        raw = json.dumps(cmd()).replace('"decim": 10', '"decim": ' + tok)
+        assert '"decim": ' + tok in raw
+        assert nacked(None, "JSON", raw), tok
+    # list elements are narrowed to int: range-checked first (2^32+5 must not become 5)
+    for key, bad in [("freq", 2 ** 32 + 5), ("freq", -2 ** 31), ("chirp_f", 2 ** 31), ("swipe_s", -2 ** 40)]:
+        c = cmd()
+        c["A_RX2"][key] = [bad]
+        assert nacked(c, key), (key, bad)
+    # INT_MIN + 1 is representable and its magnitude is too: accepted for DIRECT (not Nyquist-checked)
+    c = cmd()
+    c["A_RX2"]["freq"] = [-(2 ** 31) + 1, 5]
+    h = parse(gsdr_lib, json.dumps(c))
+    assert h
+    gsdr_lib.gsdr_command_free(h)
+    # a TX tone comb with fewer amplitudes (or frequencies) than wave_type entries
+    c = cmd()
+    assert c["A_TXRX"]["mode"] == "TX" and c["A_TXRX"]["wave_type"] == ["TONES", "TONES"]
+    c["A_TXRX"]["ampl"] = [0.5]
+    assert nacked(c, "does not match")
+    c = cmd()
+    c["A_TXRX"]["ampl"] = []
+    assert nacked(c, "does not match")
+    # the untouched command still parses
+    h = parse(gsdr_lib, json.dumps(cmd()))
+    assert h
+    gsdr_lib.gsdr_command_free(h)

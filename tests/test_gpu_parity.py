@@ -781,6 +781,64 @@ def test_pipelined_submit_wait_equals_process(cuda_device, gsdr_lib, engine):
         b.close()
 
 
+@pytest.mark.parametrize("mode", ["direct", "tones"])
+def test_mixed_entries_and_streams_keep_the_stream_state_in_order(cuda_device, gsdr_lib, monkeypatch, mode):
+    """The FIR carry, the scale slots, the raw windows and the head/tail copies pass from call
+    to call ON THE DEVICE.  Calls that arrive on different streams -- process_device on two
+    user streams, submit_device in between, with buffers outstanding -- must still see their
+    predecessor's state: every call first joins the streams the earlier ones used (one event,
+    nothing on the usual path).  A busy neighbour keeps the 'old' stream late, so a missing
+    wait shows as wrong first rows.  Bit-equal to the same buffers through one in-order stream."""
+    import torch
+    monkeypatch.setenv("GSDR_DDC_MFMA", "1")
+    monkeypatch.setenv("GSDR_MFMA_ASM", "2")
+    rng = np.random.default_rng(2718)
+    if mode == "direct":
+        N, rate, M, F, L = 96, 10_000_000, 100, 4, 100_000
+        freq = rng.choice(np.arange(-rate // 2 + 1, rate // 2), size=N, replace=False)
+        a, b = make_direct(freq, rate, M, F, L), make_direct(freq, rate, M, F, L)
+    else:
+        N, rate, nfft, F, L = 40, 1_000_000, 100, 4, 100_037
+        freq = [int(k * (rate // nfft)) for k in range(-20, 20)]
+        a, b = make_pfb(freq, rate, nfft, F, L), make_pfb(freq, rate, nfft, F, L)
+    nbuf = 14
+    xs = [torch.from_numpy(crandn(rng, L) * np.float32(10.0 ** rng.uniform(-2, 2))).to(cuda_device) for _ in range(nbuf)]
+    want = []
+    for x in xs:
+        out = torch.empty(a.out_capacity, dtype=torch.complex64, device=cuda_device)
+        n = a.process_device(x, out)
+        torch.cuda.synchronize()
+        want.append(out[:n].cpu().numpy())
+    s1, s2 = torch.cuda.Stream(cuda_device), torch.cuda.Stream(cuda_device)
+    ballast = torch.randn(4096, 4096, device=cuda_device)
+    outs = [torch.empty(b.out_capacity, dtype=torch.complex64, device=cuda_device) for _ in range(nbuf)]
+    lens, pending = [None] * nbuf, []
+    pattern = ["s1", "s2", "sub", "sub", "s1", "sub", "s2", "s2", "sub", "sub", "sub", "s1", "sub", "s2"]
+    torch.cuda.synchronize()
+    for k, how in enumerate(pattern):
+        if how == "sub":
+            if len(pending) == 3:
+                j = pending.pop(0)
+                lens[j] = b.wait()
+            b.submit_device(xs[k], outs[k])
+            pending.append(k)
+        else:
+            st = s1 if how == "s1" else s2
+            with torch.cuda.stream(st):
+                for _ in range(3):
+                    ballast = ballast @ ballast * 1e-4      # keeps this stream busy for a while
+            lens[k] = b.process_device(xs[k], outs[k], st)
+    while pending:
+        j = pending.pop(0)
+        lens[j] = b.wait()
+    torch.cuda.synchronize()
+    for k in range(nbuf):
+        assert lens[k] == want[k].size, (k, pattern[k])
+        np.testing.assert_array_equal(outs[k][:lens[k]].cpu().numpy(), want[k], err_msg=f"buffer {k} via {pattern[k]}")
+    a.close()
+    b.close()
+
+
 @pytest.mark.parametrize("overlap,streams", [("1", "2"), ("1", "3"), ("0", "2")])
 def test_pipelined_submit_device_overlapping_buffers(cuda_device, gsdr_lib, oracle_mod, monkeypatch, overlap,
                                                      streams):

@@ -143,6 +143,12 @@ static bool run_measurement(const gsdr_command *cmd, int data_fd, int device) {
             const long long L = F.rx.buffer_len;
             // software TX -> RX loop-back
             if (F.has_tx && F.tx.n_wave_type > 0 && F.tx.wave_type[0] == GSDR_TONES) {
+                // (gsdr_command_parse has checked this already; the source reads n entries of both)
+                if (F.txi.n_ampl < F.tx.n_wave_type || F.tx.n_freq < F.tx.n_wave_type) {
+                    std::fprintf(stderr, "ERROR: TX TONES needs one ampl and one freq per wave_type entry\n");
+                    ok = false;
+                    break;
+                }
                 std::vector<float> phase((size_t)F.tx.n_wave_type, 0.f);
                 gsdr_source_tones(F.d_in, L, F.produced, F.tx.rate, F.tx.freq, F.txi.ampl, phase.data(),
                                   F.tx.n_wave_type, 0.f, 0, nullptr);
