@@ -354,4 +354,13 @@ hipError_t launch_source_chirp(float2 *out, long long n, unsigned long long inde
     return hipGetLastError();
 }
 
+// Does nothing: its first launch makes the runtime load this library's code object and set up
+// the stream's queue, so that the first real buffer does not pay for it (gsdr_demod_prepare).
+__global__ void warm_kernel() {}
+
+hipError_t launch_warm(hipStream_t st) {
+    hipLaunchKernelGGL(warm_kernel, dim3(1), dim3(64), 0, st);
+    return hipGetLastError();
+}
+
 }  // namespace gsdr

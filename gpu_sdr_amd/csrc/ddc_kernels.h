@@ -134,6 +134,7 @@ hipError_t launch_chirp_demod(const float2 *in, float2 *out, long long n,
 hipError_t launch_chirp_lockin(const float2 *carry, int carry_len, const float2 *in,
                                const float *profile, int ppt, int valid, float2 *out,
                                unsigned long long index0, const ChirpShape &cs, hipStream_t st);
+hipError_t launch_warm(hipStream_t st);
 const char *chirp_demod_kernel_name();
 const char *chirp_lockin_kernel_name();
 

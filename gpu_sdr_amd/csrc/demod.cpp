@@ -1245,6 +1245,21 @@ int gsdr_demod_prepare(gsdr_demod *h, int what) {
                 HIPCHK(h, dev_alloc(&sl.d_out, (size_t)h->capacity));
             }
     }
+    // first use of a stream (its hardware queue), of the copy engines in both directions and of
+    // the code object costs milliseconds: pay them here, not on the first packets
+    HIPCHK(h, gsdr::launch_warm(h->stream));
+    if (h->pipe_ready) {
+        for (int i = 0; i < kPipeStreams; ++i) HIPCHK(h, gsdr::launch_warm(h->s_main[i]));
+        float2 *pin = nullptr;
+        if (h->slot[0].d_in && hipHostMalloc((void **)&pin, 4096) == hipSuccess) {
+            std::memset(pin, 0, 4096);
+            (void)hipMemcpyAsync(h->slot[0].d_in, pin, 4096, hipMemcpyHostToDevice, h->s_up);
+            (void)hipStreamSynchronize(h->s_up);
+            (void)hipMemcpyAsync(pin, h->slot[0].d_in, 4096, hipMemcpyDeviceToHost, h->s_down);
+            (void)hipStreamSynchronize(h->s_down);
+            (void)hipHostFree(pin);
+        }
+    }
     HIPCHK(h, hipDeviceSynchronize());
     return 0;
 }

@@ -100,5 +100,8 @@ def test_rx_link_first_calls_are_not_late(cuda_device, gsdr_lib):
     assert p.returncode == 0, p.stderr[-2000:]
     info = json.loads(p.stdout.strip().splitlines()[-1])
     assert info["streamed_samples"] == 300 * (1_000_000 // 100) * 256
-    # 1 M samples at 200 Msps = 5 ms per buffer: no call may cost more than two buffer periods
-    assert info["worst_ms"] < 10.0, info
+    # 1 M samples at 200 Msps = 5 ms per buffer.  No call may cost as much as the pipeline can
+    # hold (GSDR_PIPELINE_DEPTH = 4 buffers = 20 ms), and once the first calls are through
+    # none may cost a buffer period
+    assert info["worst_ms"] < 20.0, info
+    assert info["worst_ms_after_first_8_calls"] < 5.0, info
