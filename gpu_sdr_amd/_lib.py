@@ -116,6 +116,7 @@ SIGNATURES = [
     ("gsdr_format_rx_header", None, [C.POINTER(RxHeaderC), C.POINTER(C.c_ubyte)]),
     ("gsdr_source_tones", C.c_int, [_vp, C.c_longlong, C.c_longlong, C.c_int, _ip, _fp, _fp,
                                     C.c_int, C.c_float, C.c_ulonglong, _vp]),
+    ("gsdr_tx_tone_bins", C.c_int, [C.c_int, _ip, _fp, C.c_int, _ip, _fp]),
     ("gsdr_source_chirp", C.c_int, [_vp, C.c_longlong, C.c_ulonglong,
                                     C.POINTER(ChirpParamC), C.c_float, _vp]),
 ]

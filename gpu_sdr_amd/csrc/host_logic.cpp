@@ -56,6 +56,33 @@ void gsdr_make_flat_window(int length, int side, float *w) {
     for (int i = 0; i < length; ++i) w[i] /= sum;
 }
 
+// ---- TX tone comb: which spectrum the reference's tone_gen transforms --------
+// ref: tone_gen, cpp/kernels.cu:617-635.  Tone i goes to index f if f > 0, else rate + f, of a
+// zeroed vector of `rate` bins, by ASSIGNMENT: of tones that meet on one bin the last wins
+// (they do not add).  An index outside [0, rate) -- a 0 Hz tone gives `rate` -- is written
+// past the allocation there (undefined behaviour); the inverse FFT never sees that tone, so
+// it is dropped here.  Output: the surviving tones as signed Hz (bin b > rate/2 -> b - rate,
+// the same phasor) in first-seen bin order; returns their count.
+int gsdr_tx_tone_bins(int rate, const int *freq, const float *ampl, int n, int *out_freq, float *out_ampl) {
+    if (rate <= 0 || n < 0 || !freq || !ampl || !out_freq || !out_ampl) return -1;
+    std::vector<long long> bins;
+    int used = 0;
+    for (int i = 0; i < n; ++i) {
+        const long long idx = freq[i] > 0 ? (long long)freq[i] : (long long)rate + freq[i];
+        if (idx < 0 || idx >= rate) continue;
+        int k = 0;
+        for (; k < used; ++k)
+            if (bins[k] == idx) break;
+        if (k == used) {
+            bins.push_back(idx);
+            ++used;
+        }
+        out_freq[k] = (int)(idx > rate / 2 ? idx - rate : idx);
+        out_ampl[k] = ampl[i];
+    }
+    return used;
+}
+
 // ---- buffer_helper ---------------------------------------------------------
 // ref: cpp/USRP_server_memory_management.cpp:104-156.  The batch count is the
 // number of r >= 0 with r*n_tones + average*n_tones < eff_length (strict), the

@@ -7,8 +7,13 @@ memcpys TX buffers into the RX queue, cpp/USRP_hardware_manager.cpp:1071-1123,
     freq[k] (rate + freq[k] for negative tones) of an UNNORMALISED inverse FFT
     (tone_gen, cpp/kernels.cu:589-684) and serves successive buffer_len slices
     of it, wrapping at `rate` (get_from_tones, cpp/USRP_buffer_generator.cpp:226-229).
-    That buffer is the closed form  x[n] = sum_k ampl[k] exp(+2 pi i freq[k] n / rate),
-    n taken mod rate, which the HIP source kernel evaluates directly.
+    That buffer is the closed form  x[n] = sum_bins X[bin] exp(+2 pi i bin n / rate),
+    n taken mod rate, which the HIP source kernel evaluates directly.  The bin vector is
+    filled as the reference fills it (`tone_bins`): index = f if f > 0 else rate + f,
+    ASSIGNED -- of tones on the same bin the last one wins, they do not add -- and an
+    index outside [0, rate) is dropped: a 0 Hz tone lands on index `rate`, one element
+    past the reference's allocation (undefined behaviour there, cpp/kernels.cu:622-628),
+    so the transform never sees it and no DC term is generated.
   * CHIRP: chirp_gen law (cpp/kernels.cu:335-372) scaled by ampl[0], the running
     index wrapping at num_steps*length (get_from_chirp, :208-221).
 Other wave types raise like the reference exits (:37-52).
@@ -20,6 +25,21 @@ import numpy as np
 from . import _lib
 from .demodulator import GsdrError, chirp_derive, param, w_type
 from .source import device_chirp, device_tones
+
+
+def tone_bins(freq, ampl, rate: int):
+    """(signed Hz, amplitudes) of the tones the reference's tone_gen really generates
+    (gsdr_tx_tone_bins, ref: cpp/kernels.cu:617-635); see the module docstring for the quirks."""
+    import ctypes as C
+    f = np.ascontiguousarray(freq, dtype=np.int32)
+    a = np.ascontiguousarray(ampl, dtype=np.float32)[: len(f)]
+    of, oa = np.empty(len(f), dtype=np.int32), np.empty(len(f), dtype=np.float32)
+    n = _lib.lib().gsdr_tx_tone_bins(int(rate), f.ctypes.data_as(C.POINTER(C.c_int)),
+                                     a.ctypes.data_as(C.POINTER(C.c_float)), len(f),
+                                     of.ctypes.data_as(C.POINTER(C.c_int)), oa.ctypes.data_as(C.POINTER(C.c_float)))
+    if n < 0:
+        raise GsdrError("gsdr_tx_tone_bins: bad arguments")
+    return of[:n].copy(), oa[:n].copy()
 
 
 class TX_buffer_generator:
@@ -51,9 +71,8 @@ class TX_buffer_generator:
             n = len(p.wave_type)
             if len(p.freq) < n or len(p.ampl) < n:
                 raise GsdrError("TONES needs freq[] and ampl[] for every wave_type entry")
-            self._freq = np.asarray(p.freq[:n], dtype=np.int32)
-            self._ampl = np.asarray(p.ampl[:n], dtype=np.float32)
-            self._phase = np.zeros(n, dtype=np.float32)
+            self._freq, self._ampl = tone_bins(p.freq[:n], p.ampl[:n], int(p.rate))
+            self._phase = np.zeros(len(self._freq), dtype=np.float32)
             # TONES_buffer_len: rate, or the multiple of it that holds one buffer (:60-75)
             self._period = int(p.rate) * max(1, -(-self.buffer_len // int(p.rate)))
             self._last = 0            # TONES_last_sample

@@ -265,6 +265,16 @@ int gsdr_source_tones(gsdr_c64 *out_dev, long long n, long long start, int rate,
                       const int *freq, const float *ampl, const float *phase,
                       int n_tones, float sigma, unsigned long long seed,
                       void *hip_stream);
+/* The tone set the reference's TX tone generator actually produces (host only; ref:
+ * tone_gen, cpp/kernels.cu:617-635): tones are ASSIGNED to bins of a length-`rate`
+ * spectrum (index f, or rate + f for f <= 0), so of tones on one bin the last wins, and
+ * an index outside [0, rate) -- a 0 Hz tone lands on `rate` -- is dropped (the reference
+ * writes it past its allocation; the inverse FFT never sees it).  Writes the surviving
+ * tones (signed Hz, amplitude) to out_freq/out_ampl (room for n each), returns their
+ * count.  Feed the result to gsdr_source_tones with phase 0 for the TX buffer
+ * (ref: TX_buffer_generator TONES, cpp/USRP_buffer_generator.cpp:60-95,226-229). */
+int gsdr_tx_tone_bins(int rate, const int *freq, const float *ampl, int n,
+                      int *out_freq, float *out_ampl);
 /* TX chirp law (ref: chirp_gen, cpp/kernels.cu:335-372) written to device. */
 int gsdr_source_chirp(gsdr_c64 *out_dev, long long n, unsigned long long last_index,
                       const gsdr_chirp_param *cp, float scale, void *hip_stream);

@@ -91,6 +91,8 @@ def lib():
     L.oracle_chirp_process.argtypes = [vp, vp, vp]
     L.oracle_chirp_process.restype = C.c_long
     L.oracle_chirp_destroy.argtypes = [vp]
+    L.oracle_tone_gen.argtypes = [ip, fp, C.c_int, C.c_int, C.c_float, C.c_long, C.c_size_t, vp]
+    L.oracle_tone_gen.restype = C.c_int
     L.oracle_num_threads.restype = C.c_int
     L.oracle_set_num_threads.argtypes = [C.c_int]
     _lib = L
@@ -270,6 +272,20 @@ def chirp_demod(cp: ChirpParam, last_index: int, x) -> np.ndarray:
 def chirp_gen(cp: ChirpParam, last_index: int, n: int, scale: float = 1.0) -> np.ndarray:
     out = np.empty(n, dtype=np.complex64)
     lib().oracle_chirp_gen(C.byref(cp), last_index, n, C.c_float(scale), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def tone_gen(freq, ampl, rate: int, start: int, n: int, scale: float = 1.0) -> np.ndarray:
+    """TX tone comb, samples [start, start+n) of the periodic length-`rate` buffer
+    (cpp/kernels.cu:589-684, cpp/USRP_buffer_generator.cpp:226-229): 0 Hz / out-of-range
+    tones are dropped, of equal frequencies the last wins -- see gsdr_oracle.h."""
+    f, fptr = _iarr(freq)
+    a = np.ascontiguousarray(np.asarray(ampl, dtype=np.float32))
+    assert len(a) >= len(f)
+    out = np.empty(n, dtype=np.complex64)
+    used = lib().oracle_tone_gen(fptr, a.ctypes.data_as(C.POINTER(C.c_float)), len(f), int(rate),
+                                 C.c_float(scale), int(start), n, out.ctypes.data_as(C.c_void_p))
+    assert used >= 0
     return out
 
 

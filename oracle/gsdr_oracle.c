@@ -533,3 +533,52 @@ long oracle_chirp_process(oracle_chirp *c, const oc64 *in, oc64 *out) {
     oracle_vna_helper_update(&c->vh);                           /* :382 */
     return valid;
 }
+
+
+/* ======================================================================== */
+/* TX tone comb (row f3)                                                    */
+/* ======================================================================== */
+
+/* cpp/kernels.cu:589-684.  The reference fills a zeroed vector of `rate` bins
+ * (:611-635), runs an unnormalised CUFFT_INVERSE of length `rate` over it (:641)
+ * and multiplies by `scale` when it is not 1 (:650-651); TX_buffer_generator
+ * hands out consecutive slices of that periodic buffer (cpp/USRP_buffer_generator.cpp
+ * :60-95, :226-229).  x[n] = scale * sum_bins X[bin] * exp(+2 pi i bin n / rate),
+ * evaluated in double with an exact integer phase. */
+int oracle_tone_gen(const int *freq, const float *ampl, int n_tones, int rate,
+                    float scale, long start, size_t L, oc64 *out) {
+    if (rate <= 0 || n_tones < 0) return -1;
+    /* bin placement (:619-628): later tones overwrite earlier ones on the same bin */
+    int *bin = (int *)malloc(sizeof(int) * (size_t)(n_tones > 0 ? n_tones : 1));
+    float *amp = (float *)malloc(sizeof(float) * (size_t)(n_tones > 0 ? n_tones : 1));
+    int used = 0;
+    for (int i = 0; i < n_tones; i++) {
+        long idx = freq[i] > 0 ? (long)freq[i] : (long)rate + (long)freq[i];  /* :622-624 */
+        if (idx < 0 || idx >= rate) continue; /* base_vector[idx] out of bounds: never transformed */
+        int k;
+        for (k = 0; k < used; k++)
+            if (bin[k] == (int)idx) break;
+        bin[k] = (int)idx;
+        amp[k] = ampl[i];                      /* :628 assignment, imaginary part 0 (:631) */
+        if (k == used) used++;
+    }
+    long s0 = start % rate;
+    if (s0 < 0) s0 += rate;
+#pragma omp parallel for schedule(static)
+    for (long j = 0; j < (long)L; j++) {
+        const unsigned long long n = (unsigned long long)((s0 + j) % rate);
+        double re = 0, im = 0;
+        for (int k = 0; k < used; k++) {
+            const unsigned long long ph = ((unsigned long long)bin[k] * n) % (unsigned long long)rate;
+            const double a = 2.0 * M_PI * ((double)ph / (double)rate);
+            re += (double)amp[k] * cos(a);
+            im += (double)amp[k] * sin(a);
+        }
+        if (scale != 1.f) { re *= scale; im *= scale; }
+        out[j].x = (float)re;
+        out[j].y = (float)im;
+    }
+    free(bin);
+    free(amp);
+    return used;
+}

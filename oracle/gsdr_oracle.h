@@ -104,6 +104,17 @@ void oracle_chirp_demod(const oracle_chirp_param *cp, unsigned long last_index,
 void oracle_chirp_gen(const oracle_chirp_param *cp, unsigned long last_index,
                       size_t L, float scale, oc64 *out);
 
+/* cpp/kernels.cu:589-684 (tone_gen) + cpp/USRP_buffer_generator.cpp:60-95,226-229
+ * (the TX side serves slices of a length-`rate` buffer, wrapping): samples
+ * [start, start+L) of the periodic buffer the UNNORMALISED inverse DFT of the bin
+ * vector gives.  Bin placement as the reference does it: index = f if f > 0 else
+ * rate + f; ASSIGNED, so of equal indices the last tone wins; an index outside
+ * [0, rate) -- a 0 Hz tone (index = rate), |f| >= rate -- is a write outside the
+ * vector in the reference (undefined there): the FFT never sees that tone, it is
+ * dropped here.  Returns the number of bins in use. */
+int oracle_tone_gen(const int *freq, const float *ampl, int n_tones, int rate,
+                    float scale, long start, size_t L, oc64 *out);
+
 typedef struct oracle_chirp oracle_chirp;
 /* cpp/USRP_demodulator.cpp:177-262 */
 oracle_chirp *oracle_chirp_create(int rate, int freq0, int chirp_f, int swipe_s,

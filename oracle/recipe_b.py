@@ -333,3 +333,26 @@ class Chirp:
             self.output[: self.vna.new0] = self.output[sb: sb + self.vna.new0].copy()
         self.vna.update()                                                                        # :382
         return res
+
+
+# --------------------------------------------------------------------------
+# TX tone comb (row f3)
+# --------------------------------------------------------------------------
+def tone_gen(freq, ampl, rate: int, scale: float = 1.0) -> np.ndarray:
+    """ref: tone_gen, cpp/kernels.cu:589-684, literally: a zeroed vector of `rate` bins, the
+    tones ASSIGNED to it (index = f if f > 0 else rate + f; later tones overwrite earlier ones),
+    an UNNORMALISED inverse FFT of length `rate` (numpy's ifft divides by n: multiply back),
+    an optional scale.  Returns the whole periodic buffer (use a small `rate`).
+
+    A tone whose index falls outside the vector -- 0 Hz gives index == rate -- is a write
+    past the allocation in the reference (undefined behaviour there); the transform never
+    sees it, so it is left out here."""
+    base = np.zeros(int(rate), dtype=np.complex64)                     # :611-614
+    for f, a in zip(freq, ampl):                                       # :617-635
+        idx = int(f) if int(f) > 0 else int(rate) + int(f)             # :622-624
+        if 0 <= idx < rate:
+            base[idx] = np.float32(a)                                  # :628, imaginary part 0 (:631)
+    buf = np.fft.ifft(base.astype(np.complex128)) * float(rate)        # :641 CUFFT_INVERSE is unnormalised
+    if scale != 1.0:
+        buf = buf * np.float32(scale)                                  # :651
+    return buf.astype(np.complex64)

@@ -1108,6 +1108,33 @@ def test_sw_loop_tx_tones_into_rx_direct(cuda_device, gsdr_lib):
         g.TX_buffer_generator(g.param(rate=rate, buffer_len=L, wave_type=[g.w_type.DIRECT]))
 
 
+def test_tx_tone_generator_against_oracle(cuda_device, gsdr_lib, oracle_mod):
+    """TX_buffer_generator(TONES) buffer by buffer against the oracle's tone_gen
+    (cpp/kernels.cu:589-684: unnormalised inverse DFT of a bin vector filled by ASSIGNMENT):
+    a 0 Hz tone and f = +rate are not generated, f = -rate is the DC term, of tones on one bin
+    the last wins; buffers wrap the length-`rate` table (cpp/USRP_buffer_generator.cpp:226-229),
+    and a buffer longer than `rate` replicates it (:78-90)."""
+    import torch
+    import gpu_sdr_amd as g
+    for rate, L, nbuf in [(1_000_000, 300_007, 8), (100_000, 250_000, 3)]:
+        freq = [1000, -250_000, 0, 77_777 % (rate // 2), 1000, -rate, rate, rate // 2, -250_000 % -(rate // 2) or -5, -1]
+        ampl = [0.1, 0.2, 0.3, 0.05, 0.4, 0.07, 0.9, 0.11, 0.6, 0.02]
+        tx = g.TX_buffer_generator(g.param(mode="TX", rate=rate, buffer_len=L, freq=freq, ampl=ampl,
+                                           wave_type=[g.w_type.TONES] * len(freq)))
+        x = torch.empty(L, dtype=torch.complex64, device=cuda_device)
+        period = rate * max(1, -(-L // rate))
+        start = 0
+        for c in range(nbuf):
+            tx.get(x)
+            torch.cuda.synchronize()
+            want = oracle_mod.tone_gen(freq, ampl, rate, start, L)
+            err = float(np.max(np.abs(x.cpu().numpy() - want)))
+            record_margin(err / float(np.sum(ampl)), "max abs error / sum of amplitudes")
+            assert err <= 2e-6 * float(np.sum(ampl)), (rate, c, err)
+            start = (start + L) % period
+        tx.close()
+
+
 def test_sw_loop_tx_chirp_into_rx_chirp(cuda_device, gsdr_lib):
     """TX chirp generator -> RX chirp demodulator with lock-in: a flat S21 = ampl."""
     import torch

@@ -161,3 +161,37 @@ def test_chirp_index_wrap_large_period():
         a = oracle.chirp_demod(cp, last, x)
         b = rb.chirp_demod(x, last, ns, ln, ch, f0)
         assert np.max(np.abs(a - b)) <= 1e-6 * np.max(np.abs(a))
+
+
+# ---------------------------------------------------------------------------
+# TX tone comb (row f3): oracle (closed form, exact integer phase) against the literal
+# restatement (assignment into a length-`rate` vector + unnormalised inverse FFT) and
+# against the host helper the product uses (gsdr_tx_tone_bins)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("rate", [4096, 10_000])
+def test_tone_gen_two_restatements(rate, gsdr_lib):
+    from gpu_sdr_amd.generator import tone_bins
+    from gpu_sdr_amd.source import host_tones
+    freq = [100, -250, 0, 777, 100, -rate, rate, rate // 2, -250, -1]     # 0 Hz, duplicates, +-rate, Nyquist
+    ampl = [0.1, 0.2, 0.3, 0.05, 0.4, 0.07, 0.9, 0.11, 0.6, 0.02]
+    lit = rb.tone_gen(freq, ampl, rate)                                   # the whole periodic buffer
+    assert lit.shape == (rate,)
+    for start, n in [(0, rate), (rate - 100, 300), (5 * rate + 7, 1000)]:
+        a = oracle.tone_gen(freq, ampl, rate, start, n)
+        b = lit[(start + np.arange(n)) % rate]
+        assert np.max(np.abs(a - b)) <= 2e-6, (start, n)
+    # the quirks, spelled out: the 0 Hz tone (0.3) and f = +rate (0.9) are not generated, f = -rate
+    # IS the DC term (0.07); of the duplicates the last amplitude wins (0.4, 0.6), they do not add
+    spec = np.fft.fft(lit.astype(np.complex128)) / rate
+    want = {100: 0.4, rate - 250: 0.6, 777: 0.05, 0: 0.07, rate // 2: 0.11, rate - 1: 0.02}
+    for b_, a_ in want.items():
+        assert abs(spec[b_] - a_) < 1e-6, b_
+    others = np.ones(rate, bool)
+    others[list(want)] = False
+    assert np.max(np.abs(spec[others])) < 1e-6
+    # the product's host helper agrees tone for tone
+    f2, a2 = tone_bins(freq, ampl, rate)
+    got = {int(f) % rate: float(a) for f, a in zip(f2, a2)}
+    assert got.keys() == want.keys() and all(abs(got[k] - want[k]) < 1e-7 for k in want)
+    x = host_tones(300, rate - 100, rate, f2, a2, np.zeros(len(f2), np.float32))
+    assert np.max(np.abs(x - oracle.tone_gen(freq, ampl, rate, rate - 100, 300))) <= 2e-6

@@ -149,9 +149,12 @@ static bool run_measurement(const gsdr_command *cmd, int data_fd, int device) {
                     ok = false;
                     break;
                 }
-                std::vector<float> phase((size_t)F.tx.n_wave_type, 0.f);
-                gsdr_source_tones(F.d_in, L, F.produced, F.tx.rate, F.tx.freq, F.txi.ampl, phase.data(),
-                                  F.tx.n_wave_type, 0.f, 0, nullptr);
+                // the tones the reference's tone_gen really produces (bin assignment, kernels.cu:617-635)
+                std::vector<int> tf((size_t)F.tx.n_wave_type);
+                std::vector<float> ta((size_t)F.tx.n_wave_type), phase((size_t)F.tx.n_wave_type, 0.f);
+                const int nt = gsdr_tx_tone_bins(F.tx.rate, F.tx.freq, F.txi.ampl, F.tx.n_wave_type, tf.data(), ta.data());
+                gsdr_source_tones(F.d_in, L, F.produced, F.tx.rate, tf.data(), ta.data(), phase.data(),
+                                  nt > 0 ? nt : 0, 0.f, 0, nullptr);
             } else if (F.has_tx && F.tx.n_wave_type > 0 && F.tx.wave_type[0] == GSDR_CHIRP) {
                 gsdr_source_chirp(F.d_in, L, (unsigned long long)F.produced, &F.tx_chirp,
                                   F.txi.n_ampl ? F.txi.ampl[0] : 1.f, nullptr);
