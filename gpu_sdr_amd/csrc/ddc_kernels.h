@@ -102,6 +102,7 @@ struct MfmaPlan {
     int TT, PK;                // tone tiles per wave (1, 2), phasor block (16, 32)
     int ntg, nk8, MF, M;
     unsigned rate;
+    bool x16;                  // phasor images in the v_mfma_f32_16x16x32_f16 layout (AsmRing16)
 };
 
 void mfma_build_tables(const MfmaPlan &pl, const std::vector<unsigned> &fmod_in, const float *window,
@@ -115,7 +116,7 @@ hipError_t launch_absmax(const float2 *x, long long n, unsigned *slots, int cur,
 // AsmRing: assembly main loop, operand shared through an LDS ring (production);
 // AsmSolo: assembly main loop, every wave converts its own operand; Cxx: compiler-scheduled
 // (TT, PK, W apply to it only; the assembly kernels are TT = 1, PK = 32, W = 4).
-enum class MfmaKernel { AsmRing, AsmSolo, Cxx, AsmRingDirect };
+enum class MfmaKernel { AsmRing, AsmSolo, Cxx, AsmRingDirect, AsmRing16 };
 hipError_t launch_ddc_mfma(MfmaKernel kind, int TT, int PK, int W, const MfmaLaunch &a, hipStream_t st);
 const char *ddc_mfma_kernel_name(MfmaKernel kind);
 

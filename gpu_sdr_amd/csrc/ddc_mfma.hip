@@ -38,6 +38,7 @@
 #include "ddc_device.h"
 #include "ddc_mfma_gen.h"
 #include "ddc_mfma_ring_gen.h"
+#include "ddc_mfma_ring16_gen.h"
 #include "ddc_mfma_ringd_gen.h"
 
 namespace gsdr {
@@ -546,6 +547,148 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The ring loop re-tiled for v_mfma_f32_16x16x32_f16 (tools/gen_ddc_mfma_ring16.py).  Under the
+// package power cap the 16x16x32 shape does the same FLOPs per cycle for less energy, i.e. at a
+// higher clock (MI355X_MICROARCH.md, DVFS give-back item 7).  Same ring, same writers; the
+// readers take each 16-row x 32-real fragment out of the unchanged slot layout through a
+// per-lane base, and the results come out as 2 x 2 tiles of 16 x 16:
+//     tile q = 2*rh + th, register j of lane l  <->  row 16*rh + 4*(l >> 4) + j,
+//                                                   tone 16*th + (l & 15) of the wave's 32.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ __attribute__((target("no-packed-fp32-ops"))) void store_tile16(
+    const MfmaLaunch &a, int gt, int tg, int lane, float invS, float2 base_self, const float16v &accr,
+    const float16v &acci) {
+    const MfmaShape &sh = a.sh;
+    const int Np = sh.NT32 * 32;
+    const int l15 = lane & 15, l4 = lane >> 4;
+#pragma unroll
+    for (int th = 0; th < 2; ++th) {
+        // lane 16*th + l15 holds the tile phasor of tone 16*th + l15 (every lane computed the one
+        // of tone lane & 31)
+        const int src = (16 * th + l15) << 2;
+        const float bx = bits_to_float((unsigned)__builtin_amdgcn_ds_bpermute(src, (int)float_to_bits(base_self.x)));
+        const float by = bits_to_float((unsigned)__builtin_amdgcn_ds_bpermute(src, (int)float_to_bits(base_self.y)));
+        const float br = bx * invS, bi = by * invS;
+        const int n = tg * 32 + 16 * th + l15;
+#pragma unroll
+        for (int rh = 0; rh < 2; ++rh)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = 4 * (2 * rh + th) + j;
+                const int row = 16 * rh + 4 * l4 + j;
+                const float2 d = a.dtab[(size_t)row * Np + n];
+                const float rr = br * d.x - bi * d.y, ri = br * d.y + bi * d.x;
+                float2 y;
+                y.x = accr[i] * rr - acci[i] * ri;
+                y.y = accr[i] * ri + acci[i] * rr;
+                const int orow = gt * 32 + row;
+                if (orow < sh.nout && n < sh.N) a.out[(size_t)orow * sh.N + n] = y;
+            }
+    }
+}
+
+__device__ __forceinline__ __attribute__((target("no-packed-fp32-ops"))) void ring16_tile(
+    const MfmaLaunch &a, uint4 *lds, int gt, int first, int se, int tg, int wave, bool active) {
+    constexpr int KS = 4;
+    const MfmaShape &sh = a.sh;
+    const int Np = sh.NT32 * 32;
+    const int nhi = timing_one_block(sh) ? 1 : (sh.nk8 + KS - 1) / KS;
+    unsigned tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = (int)(tid & 63u);
+    const int r = lane & 31, hh = lane >> 5;
+    const float S = bits_to_float((unsigned)(127 + se) << 23);
+    const unsigned to = (unsigned)((4 * hh + 8 * wave) * 4);
+    // P of the lane's two tones: tone 16*th + (lane & 15); the second one 16 tones = 128 bytes on
+    const unsigned po = (unsigned)(tg * 32 + (lane & 15)) * 8u;
+    const unsigned bo = (unsigned)tg * (KS * 4 * 1024u) + (unsigned)lane * 16u;
+    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char *)lds;
+    // readers: fragment (k2, rh, sp) = old k-step 2*k2 + (lane >> 5), old lane (16*rh + (lane & 15)) + 32*((lane >> 4) & 1)
+    const unsigned rd16 = lds_base + (unsigned)(lane >> 5) * 2048u + (unsigned)(lane & 15) * 16u +
+                          (unsigned)((lane >> 4) & 1) * 512u;
+    // writers: unchanged (wave converts old k-step `wave`, lane (row r, half hh))
+    const unsigned wr16 = lds_base + (unsigned)lane * 16u + (unsigned)wave * 2048u;
+    const unsigned accaddr = lds_base + (unsigned)wave * 8192u + (unsigned)lane * 16u;
+    const unsigned long long tpb = (unsigned long long)a.taps, ppb = (unsigned long long)a.ptab,
+                             bfb = (unsigned long long)a.bfrag;
+    const int o = gt * 32 + r;
+    const int oc = o < sh.nout ? o : sh.nout - 1;
+    const float2 *xbase;
+    long long xshift;
+    if (gt == 0) {
+        xbase = a.head;
+        xshift = sh.carry_len;
+    } else if (gt == sh.ngt - 1) {
+        xbase = a.tail;
+        xshift = -sh.tail0;
+    } else {
+        xbase = a.x;
+        xshift = 0;
+    }
+    const unsigned xo = (unsigned)((((long long)(oc + sh.woff) * sh.M + xshift) + 4 * hh + 8 * wave) * 8);
+    const unsigned long long xb = (unsigned long long)xbase;
+    asm volatile(GSDR_MFMA_RING16_TEXT
+                 :
+                 : [xo] "v"(xo), [to] "v"(to), [po] "v"(po), [bo] "v"(bo), [lane16] "v"(rd16), [wr16] "v"(wr16),
+                   [accaddr] "v"(accaddr), [xb_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)xb)),
+                   [xb_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(xb >> 32))),
+                   [tp_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)tpb)),
+                   [tp_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(tpb >> 32))),
+                   [pp_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)ppb)),
+                   [pp_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(ppb >> 32))),
+                   [bf_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)bfb)),
+                   [bf_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(bfb >> 32))),
+                   [pstride] "s"(__builtin_amdgcn_readfirstlane((int)((unsigned)Np * 8u))),
+                   [nhi] "s"(__builtin_amdgcn_readfirstlane(nhi)),
+                   [first] "s"(__builtin_amdgcn_readfirstlane(first)),
+                   [scale] "v"(S)
+                 : GSDR_MFMA_RING16_CLOBBERS);
+    if (active && !timing_no_stores(sh)) {
+        unsigned tid2 = threadIdx.x;
+        asm volatile("" : "+v"(tid2));
+        const int lane2 = (int)(tid2 & 63u);
+        const float invS = bits_to_float((unsigned)(127 - se) << 23) * sh.unscale;
+        float16v accr, acci;
+        const float4v *acc = reinterpret_cast<const float4v *>(lds) + wave * 512 + lane2;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const float4v vr = acc[qd * 64], vi = acc[(qd + 4) * 64];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                accr[qd * 4 + j] = vr[j];
+                acci[qd * 4 + j] = vi[j];
+            }
+        }
+        const int n_self = tg * 32 + (lane2 & 31);
+        store_tile16(a, gt, tg, lane2, invS, tile_phasor(a, gt, a.fmod[n_self]), accr, acci);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops"))) void ddc_mfma_ring16_kernel(
+    const MfmaLaunch a) {
+    constexpr int W = 4;
+    __shared__ uint4 lds[2048];
+    static_assert(sizeof(uint4) * 2048 >= GSDR_MFMA_RING16_BYTES, "ring fits");
+    const MfmaShape &sh = a.sh;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int rt = sh.rt > 1 ? 2 : 1;
+    const int gt0 = (q / sh.ntq) * rt * 8 + xcd;
+    if (gt0 >= sh.ngt) return;
+    const int tg_raw = (q % sh.ntq) * W + wave;
+    const bool active = tg_raw < sh.ntg;
+    const int tg = active ? tg_raw : sh.ntg - 1;
+    const unsigned mb = slot_max(a.maxbits, sh.slot_cur, sh.slot_prev);
+    int se = 140 - (int)((mb >> 23) & 0xffu);
+    se = se > 100 ? 100 : (se < -100 ? -100 : se);
+    ring16_tile(a, lds, gt0, 1, se, tg, wave, active);
+    if (rt > 1 && gt0 + 8 < sh.ngt) {
+        workgroup_sync();
+        ring16_tile(a, lds, gt0 + 8, 0, se, tg, wave, active);
+    }
+}
+
 // The ring kernel without its staging pass: ONE launch per buffer.  The loop reads the
 // caller's buffer and the carry directly (tools/gen_ddc_mfma_ring.py --direct: two
 // loads under complementary EXEC masks, clamped at the end of the buffer, where only
@@ -831,6 +974,36 @@ void mfma_build_tables(const MfmaPlan &pl, const std::vector<unsigned> &fmod_in,
     //   c = 0 (real part of the product):  [ Wr, -Wi ]
     //   c = 1 (imaginary part):            [ Wi,  Wr ]
     bfrag.assign((size_t)tiles * KS * 4 * 64, uint4{0, 0, 0, 0});
+    if (pl.x16) {
+        // v_mfma_f32_16x16x32_f16: image f = ((k2*2 + th)*2 + c)*2 + sp; lane l holds tone
+        // 16*th + (l & 15) of the tile, element j <-> k = 8*(l >> 4) + j <-> sample
+        // lo = 16*k2 + 4*(l >> 4) + (j >> 1), component j & 1 (same pairing with Re/Im b as below)
+        for (int T = 0; T < tiles; ++T)
+            for (int k2 = 0; k2 < 2; ++k2)
+                for (int th = 0; th < 2; ++th)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const unsigned long long fm = fmod[(size_t)T * 32 + 16 * th + (lane & 15)];
+                        unsigned short img[2][2][8];
+                        for (int j = 0; j < 8; ++j) {
+                            const int lo = 16 * k2 + 4 * (lane >> 4) + (j >> 1);
+                            double wr, wi;
+                            host_phasor((fm * (unsigned long long)lo) % rate, rate, wr, wi);
+                            const float v[2] = {(j & 1) ? (float)-wi : (float)wr, (j & 1) ? (float)wr : (float)wi};
+                            for (int c = 0; c < 2; ++c) {
+                                const unsigned short hb = to_half_bits(v[c]);
+                                img[c][0][j] = hb;
+                                img[c][1][j] = to_half_bits(v[c] - from_half_bits(hb));
+                            }
+                        }
+                        for (int c = 0; c < 2; ++c)
+                            for (int sp = 0; sp < 2; ++sp) {
+                                uint4 w;
+                                __builtin_memcpy(&w, img[c][sp], 16);
+                                const int f = ((k2 * 2 + th) * 2 + c) * 2 + sp;
+                                bfrag[((size_t)T * 16 + f) * 64 + lane] = w;
+                            }
+                    }
+    } else
     for (int T = 0; T < tiles; ++T)
         for (int ks = 0; ks < KS; ++ks)
             for (int lane = 0; lane < 64; ++lane) {
@@ -938,6 +1111,15 @@ hipError_t launch_ddc_mfma(MfmaKernel kind, int TT, int PK, int W, const MfmaLau
         hipLaunchKernelGGL(ddc_mfma_ringd_kernel, dim3((unsigned)grid), dim3(256), 0, st, a);
         return hipGetLastError();
     }
+    if (kind == MfmaKernel::AsmRing16) {
+        if (TT != 1 || PK != 32 || W != 4 || sh.rt < 0 || sh.rt > 8) return hipErrorInvalidValue;
+        const int rt = sh.rt > 1 ? sh.rt : 1;
+        const int gt8 = ((sh.ngt + 7) / 8 + rt - 1) / rt;
+        const long long grid = (long long)gt8 * 8 * sh.ntq;
+        if (grid < 1 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(ddc_mfma_ring16_kernel, dim3((unsigned)grid), dim3(256), 0, st, a);
+        return hipGetLastError();
+    }
     if (kind == MfmaKernel::AsmRing) {
         if (TT != 1 || PK != 32 || W != 4 || sh.rt < 0 || sh.rt > 8) return hipErrorInvalidValue;
         const int rt = sh.rt > 1 ? sh.rt : 1;
@@ -964,7 +1146,7 @@ hipError_t launch_ddc_mfma(MfmaKernel kind, int TT, int PK, int W, const MfmaLau
 }
 
 const char *ddc_mfma_kernel_name(MfmaKernel kind) {
-    return kind == MfmaKernel::AsmRingDirect ? "ddc_mfma_ringd_kernel" : kind == MfmaKernel::AsmRing ? "ddc_mfma_ring_kernel" : kind == MfmaKernel::AsmSolo ? "ddc_mfma_asm_kernel" : "ddc_mfma_kernel";
+    return kind == MfmaKernel::AsmRing16 ? "ddc_mfma_ring16_kernel" : kind == MfmaKernel::AsmRingDirect ? "ddc_mfma_ringd_kernel" : kind == MfmaKernel::AsmRing ? "ddc_mfma_ring_kernel" : kind == MfmaKernel::AsmSolo ? "ddc_mfma_asm_kernel" : "ddc_mfma_kernel";
 }
 
 }  // namespace gsdr

@@ -380,6 +380,8 @@ int setup_mfma(gsdr_demod *h, bool direct, const std::vector<long long> &tone) {
     if (asm_kind == 1 && asm_shape && ((M * F + 31) / 32) * 32 + 128 <= 10240) h->mf_kind = gsdr::MfmaKernel::AsmSolo;
     // 3 = the ring kernel reading buffer and carry in place: one launch per buffer (DIRECT,
     // M % 4 == 0; other shapes fall back to 2)
+    // 4 = the ring loop on v_mfma_f32_16x16x32_f16 (tools/gen_ddc_mfma_ring16.py)
+    if (asm_kind == 4 && asm_shape) h->mf_kind = gsdr::MfmaKernel::AsmRing16;
     if (asm_kind == 3 && asm_shape)
         h->mf_kind = direct && M % 4 == 0 && h->L < 0x10000000LL ? gsdr::MfmaKernel::AsmRingDirect
                                                                   : gsdr::MfmaKernel::AsmRing;
@@ -390,6 +392,7 @@ int setup_mfma(gsdr_demod *h, bool direct, const std::vector<long long> &tone) {
     pl.MF = M * F;
     pl.nk8 = (pl.MF + 7) / 8;
     pl.rate = rate;
+    pl.x16 = h->mf_kind == gsdr::MfmaKernel::AsmRing16;
     const int nt32 = (h->ddc_channels + 31) / 32;
     pl.ntg = (nt32 + pl.TT - 1) / pl.TT;
     std::vector<unsigned> fmod_in(h->ddc_channels);
