@@ -116,7 +116,7 @@ hipError_t launch_absmax(const float2 *x, long long n, unsigned *slots, int cur,
 // AsmRing: assembly main loop, operand shared through an LDS ring (production);
 // AsmSolo: assembly main loop, every wave converts its own operand; Cxx: compiler-scheduled
 // (TT, PK, W apply to it only; the assembly kernels are TT = 1, PK = 32, W = 4).
-enum class MfmaKernel { AsmRing, AsmSolo, Cxx, AsmRingDirect, AsmRing16 };
+enum class MfmaKernel { AsmRing, AsmSolo, Cxx, AsmRingDirect, AsmRing16, AsmRing16W8 };
 hipError_t launch_ddc_mfma(MfmaKernel kind, int TT, int PK, int W, const MfmaLaunch &a, hipStream_t st);
 const char *ddc_mfma_kernel_name(MfmaKernel kind);
 

@@ -39,6 +39,7 @@
 #include "ddc_mfma_gen.h"
 #include "ddc_mfma_ring_gen.h"
 #include "ddc_mfma_ring16_gen.h"
+#include "ddc_mfma_ring16w8_gen.h"
 #include "ddc_mfma_ringd_gen.h"
 
 namespace gsdr {
@@ -108,6 +109,27 @@ __device__ __forceinline__ bool timing_one_block(const MfmaShape &sh) { return (
 #else
 __device__ __forceinline__ bool timing_no_stores(const MfmaShape &) { return false; }
 __device__ __forceinline__ bool timing_one_block(const MfmaShape &) { return false; }
+#endif
+
+// Diagnostic builds only (-DGSDR_STAMP_BUILD, scratch/stamp_probe.py): every workgroup of the
+// ring kernels leaves its start and end time (s_memrealtime, 100 MHz) and its XCC id in a buffer
+// of its own.  Nothing in the kernel reads the stamps; the shipped library has none of this.
+#ifdef GSDR_STAMP_BUILD
+__device__ unsigned long long *g_stamp_buf = nullptr;
+__device__ __forceinline__ void stamp(int slot) {
+    if (g_stamp_buf && threadIdx.x == 0) {
+        unsigned long long t = __builtin_amdgcn_s_memrealtime();
+        if (slot == 2) {
+            unsigned xcc, hwid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            t = (xcc & 0xfu) | ((unsigned long long)hwid << 8);
+        }
+        g_stamp_buf[4 * (size_t)blockIdx.x + slot] = t;
+    }
+}
+#else
+__device__ __forceinline__ void stamp(int) {}
 #endif
 
 // max |component| over this and the previous buffer: absmax_kernel keeps 16 partial
@@ -539,12 +561,15 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
     const unsigned mb = slot_max(a.maxbits, sh.slot_cur, sh.slot_prev);
     int se = 140 - (int)((mb >> 23) & 0xffu);
     se = se > 100 ? 100 : (se < -100 ? -100 : se);
+    stamp(0);
+    stamp(2);
     ring_tile(a, lds, gt0, 1, se, tg, wave, active);
     if (rt > 1 && gt0 + 8 < sh.ngt) {
         // the ring of the next tile overlays the accumulators of this one: every wave has read its own
         workgroup_sync();
         ring_tile(a, lds, gt0 + 8, 0, se, tg, wave, active);
     }
+    stamp(1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -679,6 +704,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
     const int tg_raw = (q % sh.ntq) * W + wave;
     const bool active = tg_raw < sh.ntg;
     const int tg = active ? tg_raw : sh.ntg - 1;
+    stamp(0);
+    stamp(2);
     const unsigned mb = slot_max(a.maxbits, sh.slot_cur, sh.slot_prev);
     int se = 140 - (int)((mb >> 23) & 0xffu);
     se = se > 100 ? 100 : (se < -100 ? -100 : se);
@@ -687,6 +714,114 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
         workgroup_sync();
         ring16_tile(a, lds, gt0 + 8, 0, se, tg, wave, active);
     }
+    stamp(1);
+}
+
+#ifdef GSDR_STAMP_BUILD
+extern "C" int gsdr_debug_set_stamp_buffer(void *dev_ptr) {
+    unsigned long long *p = (unsigned long long *)dev_ptr;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#endif
+
+// ---------------------------------------------------------------------------------------------
+// The 16x16x32 ring loop for workgroups of EIGHT waves (tools/gen_ddc_mfma_ring16w8.py): 32 rows x
+// 256 tones per workgroup, one workgroup per compute unit.  The two waves of a SIMD are partners
+// inside one workgroup -- the barrier of every block keeps them together and they take priority
+// in turns -- so a launch of one round has no tail in which half of the workgroups run alone
+// (the 4-wave kernels: 105 us / 145 us on every compute unit of a C3 launch, scratch/stamp_probe.py),
+// and the conversion is shared by eight waves: waves 0..3 convert the even blocks, 4..7 the odd ones.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) __attribute__((target("no-packed-fp32-ops"))) void ddc_mfma_ring16w8_kernel(
+    const MfmaLaunch a) {
+    constexpr int KS = 4, W = 8;
+    // ring (3 slots of 8 KiB) while the loop runs, then the accumulators (8 waves x 8 KiB)
+    __shared__ uint4 lds[4096];
+    static_assert(sizeof(uint4) * 4096 >= GSDR_MFMA_RING16W8_BYTES, "ring fits");
+    const MfmaShape &sh = a.sh;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int ntq8 = (sh.ntg + W - 1) / W;
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int gt = (q / ntq8) * 8 + xcd;
+    if (gt >= sh.ngt) return;
+    stamp(0);
+    stamp(2);
+    const int tg_raw = (q % ntq8) * W + wave;
+    const bool active = tg_raw < sh.ntg;      // idle waves still convert and keep the barriers
+    const int tg = active ? tg_raw : sh.ntg - 1;
+    const unsigned mb = slot_max(a.maxbits, sh.slot_cur, sh.slot_prev);
+    int se = 140 - (int)((mb >> 23) & 0xffu);
+    se = se > 100 ? 100 : (se < -100 ? -100 : se);
+    const int Np = sh.NT32 * 32;
+    const int nhi = timing_one_block(sh) ? 1 : (sh.nk8 + KS - 1) / KS;
+    unsigned tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = (int)(tid & 63u);
+    const int r = lane & 31, hh = lane >> 5;
+    const int kw = wave & 3;                  // old k-step this wave converts (in its blocks)
+    const float S = bits_to_float((unsigned)(127 + se) << 23);
+    const unsigned to = (unsigned)((4 * hh + 8 * kw) * 4);
+    const unsigned po = (unsigned)(tg * 32 + (lane & 15)) * 8u;
+    const unsigned bo = (unsigned)tg * (KS * 4 * 1024u) + (unsigned)lane * 16u;
+    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char *)lds;
+    const unsigned rd16 = lds_base + (unsigned)(lane >> 5) * 2048u + (unsigned)(lane & 15) * 16u +
+                          (unsigned)((lane >> 4) & 1) * 512u;
+    const unsigned wr16 = lds_base + (unsigned)lane * 16u + (unsigned)kw * 2048u;
+    const unsigned accaddr = lds_base + (unsigned)wave * 8192u + (unsigned)lane * 16u;
+    const unsigned long long tpb = (unsigned long long)a.taps, ppb = (unsigned long long)a.ptab,
+                             bfb = (unsigned long long)a.bfrag;
+    const int o = gt * 32 + r;
+    const int oc = o < sh.nout ? o : sh.nout - 1;
+    const float2 *xbase;
+    long long xshift;
+    if (gt == 0) {
+        xbase = a.head;
+        xshift = sh.carry_len;
+    } else if (gt == sh.ngt - 1) {
+        xbase = a.tail;
+        xshift = -sh.tail0;
+    } else {
+        xbase = a.x;
+        xshift = 0;
+    }
+    const unsigned xo = (unsigned)((((long long)(oc + sh.woff) * sh.M + xshift) + 4 * hh + 8 * kw) * 8);
+    const unsigned long long xb = (unsigned long long)xbase;
+    asm volatile(GSDR_MFMA_RING16W8_TEXT
+                 :
+                 : [xo] "v"(xo), [to] "v"(to), [po] "v"(po), [bo] "v"(bo), [lane16] "v"(rd16), [wr16] "v"(wr16),
+                   [accaddr] "v"(accaddr), [xb_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)xb)),
+                   [xb_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(xb >> 32))),
+                   [tp_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)tpb)),
+                   [tp_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(tpb >> 32))),
+                   [pp_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)ppb)),
+                   [pp_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(ppb >> 32))),
+                   [bf_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)bfb)),
+                   [bf_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(bfb >> 32))),
+                   [pstride] "s"(__builtin_amdgcn_readfirstlane((int)((unsigned)Np * 8u))),
+                   [nhi] "s"(__builtin_amdgcn_readfirstlane(nhi)),
+                   [role] "s"(__builtin_amdgcn_readfirstlane(wave >> 2)),
+                   [scale] "v"(S)
+                 : GSDR_MFMA_RING16W8_CLOBBERS);
+    if (active && !timing_no_stores(sh)) {
+        unsigned tid2 = threadIdx.x;
+        asm volatile("" : "+v"(tid2));
+        const int lane2 = (int)(tid2 & 63u);
+        const float invS = bits_to_float((unsigned)(127 - se) << 23) * sh.unscale;
+        float16v accr, acci;
+        const float4v *acc = reinterpret_cast<const float4v *>(lds) + wave * 512 + lane2;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const float4v vr = acc[qd * 64], vi = acc[(qd + 4) * 64];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                accr[qd * 4 + j] = vr[j];
+                acci[qd * 4 + j] = vi[j];
+            }
+        }
+        const int n_self = tg * 32 + (lane2 & 31);
+        store_tile16(a, gt, tg, lane2, invS, tile_phasor(a, gt, a.fmod[n_self]), accr, acci);
+    }
+    stamp(1);
 }
 
 // The ring kernel without its staging pass: ONE launch per buffer.  The loop reads the
@@ -1111,6 +1246,14 @@ hipError_t launch_ddc_mfma(MfmaKernel kind, int TT, int PK, int W, const MfmaLau
         hipLaunchKernelGGL(ddc_mfma_ringd_kernel, dim3((unsigned)grid), dim3(256), 0, st, a);
         return hipGetLastError();
     }
+    if (kind == MfmaKernel::AsmRing16W8) {
+        if (TT != 1 || PK != 32 || W != 4) return hipErrorInvalidValue;
+        const int gt8 = (sh.ngt + 7) / 8;
+        const long long grid = (long long)gt8 * 8 * ((sh.ntg + 7) / 8);
+        if (grid < 1 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(ddc_mfma_ring16w8_kernel, dim3((unsigned)grid), dim3(512), 0, st, a);
+        return hipGetLastError();
+    }
     if (kind == MfmaKernel::AsmRing16) {
         if (TT != 1 || PK != 32 || W != 4 || sh.rt < 0 || sh.rt > 8) return hipErrorInvalidValue;
         const int rt = sh.rt > 1 ? sh.rt : 1;
@@ -1146,7 +1289,7 @@ hipError_t launch_ddc_mfma(MfmaKernel kind, int TT, int PK, int W, const MfmaLau
 }
 
 const char *ddc_mfma_kernel_name(MfmaKernel kind) {
-    return kind == MfmaKernel::AsmRing16 ? "ddc_mfma_ring16_kernel" : kind == MfmaKernel::AsmRingDirect ? "ddc_mfma_ringd_kernel" : kind == MfmaKernel::AsmRing ? "ddc_mfma_ring_kernel" : kind == MfmaKernel::AsmSolo ? "ddc_mfma_asm_kernel" : "ddc_mfma_kernel";
+    return kind == MfmaKernel::AsmRing16W8 ? "ddc_mfma_ring16w8_kernel" : kind == MfmaKernel::AsmRing16 ? "ddc_mfma_ring16_kernel" : kind == MfmaKernel::AsmRingDirect ? "ddc_mfma_ringd_kernel" : kind == MfmaKernel::AsmRing ? "ddc_mfma_ring_kernel" : kind == MfmaKernel::AsmSolo ? "ddc_mfma_asm_kernel" : "ddc_mfma_kernel";
 }
 
 }  // namespace gsdr

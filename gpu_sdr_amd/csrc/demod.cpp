@@ -382,6 +382,8 @@ int setup_mfma(gsdr_demod *h, bool direct, const std::vector<long long> &tone) {
     // M % 4 == 0; other shapes fall back to 2)
     // 4 = the ring loop on v_mfma_f32_16x16x32_f16 (tools/gen_ddc_mfma_ring16.py)
     if (asm_kind == 4 && asm_shape) h->mf_kind = gsdr::MfmaKernel::AsmRing16;
+    // 5 = the same loop for workgroups of eight waves (tools/gen_ddc_mfma_ring16w8.py)
+    if (asm_kind == 5 && asm_shape) h->mf_kind = gsdr::MfmaKernel::AsmRing16W8;
     if (asm_kind == 3 && asm_shape)
         h->mf_kind = direct && M % 4 == 0 && h->L < 0x10000000LL ? gsdr::MfmaKernel::AsmRingDirect
                                                                   : gsdr::MfmaKernel::AsmRing;
@@ -392,7 +394,7 @@ int setup_mfma(gsdr_demod *h, bool direct, const std::vector<long long> &tone) {
     pl.MF = M * F;
     pl.nk8 = (pl.MF + 7) / 8;
     pl.rate = rate;
-    pl.x16 = h->mf_kind == gsdr::MfmaKernel::AsmRing16;
+    pl.x16 = h->mf_kind == gsdr::MfmaKernel::AsmRing16 || h->mf_kind == gsdr::MfmaKernel::AsmRing16W8;
     const int nt32 = (h->ddc_channels + 31) / 32;
     pl.ntg = (nt32 + pl.TT - 1) / pl.TT;
     std::vector<unsigned> fmod_in(h->ddc_channels);

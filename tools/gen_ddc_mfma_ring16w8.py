@@ -1,28 +1,23 @@
 #!/usr/bin/env python3
-"""Generates gpu_sdr_amd/csrc/ddc_mfma_ring16_gen.h: main loop of ddc_mfma_ring16_kernel
-(gfx950) -- the LDS-ring loop of tools/gen_ddc_mfma_ring.py re-tiled for
-v_mfma_f32_16x16x32_f16.
+"""Generates gpu_sdr_amd/csrc/ddc_mfma_ring16w8_gen.h: main loop of ddc_mfma_ring16w8_kernel
+(gfx950) -- the 16x16x32 ring loop of tools/gen_ddc_mfma_ring16.py for workgroups of EIGHT waves
+(32 rows x 256 tones, one workgroup per compute unit).
 
-Why: every DDC workload runs at the package power cap, and under the
-cap the 16x16x32 shape delivers 12-15 % more FLOP/s than 32x32x16 at equal cycles per FLOP
-(MI355X_MICROARCH.md, DVFS give-back item 7).  Same arithmetic, same ring, same writers:
+Why.  In-kernel stamps (scratch/stamp_probe.py) show what a launch of one round costs the 4-wave
+kernels: the two workgroups of a compute unit share its SIMDs wave by wave, the hardware serves the
+OLDER wave first at every arbitration, so on every unit one workgroup ends after 105 us of a C3
+launch and the other after 145 us -- the last 40 us alone, at half the pipe rate a pair reaches.
+Here the two waves of a SIMD are partners inside ONE workgroup: the barrier at the end of every
+block keeps them together, and they take priority in turns (s_setprio: waves 0..3 in the first
+k-step of a block, waves 4..7 in the second), so neither runs ahead and both end together.
 
-  * one wave = 32 rows x 32 tones = 2 x 2 tiles of 16 x 16, x (re, im): 8 accumulators of 4
-    registers (the 32 result registers of the 32x32 form, regrouped);
-  * a block of 32 samples = 2 k-steps of 16 samples (K = 32 reals): 48 MFMAs of 16 cycles
-    instead of 24 of 32.  A fragment (k-step k2, row half rh, hi|lo) is read from the ring
-    UNCHANGED in layout -- the writers still convert 8-sample k-steps -- with a per-lane base:
-    lane l takes old k-step 2*k2 + (l >> 5), old lane (16*rh + (l & 15)) + 32*((l >> 4) & 1);
-    conflict-free for ds_read_b128 (the 16 lanes of a service group differ in l & 15 only);
-  * MFMA order inside a k-step: (row half, hi|lo) major, so that an operand buffer is dead 8
-    or 4 MFMAs after its first use and is re-read one block later at least 24 MFMAs (384
-    cycles, the distance rule R1 was measured at) after its last use;
-  * the block phasor P exists per tone half: two dwordx2 loads per block instead of two dword
-    loads, 64 v_fma_f32 as before.
+The eight waves also share the conversion: waves 0..3 convert the even blocks (one old k-step
+each), waves 4..7 the odd ones -- 28 conversion instructions and 3 loads per wave every OTHER
+block.  On a SIMD the converting wave and the idle one are partners in every block.  The loop
+exists twice, once per role (convert in the even / in the odd block of a trip); barrier counts are
+the same on both paths.
 
-Rules R1..R4 of tools/gen_ddc_mfma.py apply unchanged.
-
-    python3 tools/gen_ddc_mfma_ring16.py > gpu_sdr_amd/csrc/ddc_mfma_ring16_gen.h
+    python3 tools/gen_ddc_mfma_ring16w8.py > gpu_sdr_amd/csrc/ddc_mfma_ring16w8_gen.h
 """
 import os
 import sys
@@ -38,7 +33,7 @@ ABLATE = set(filter(None, os.environ.get("GEN_ABLATE", "").split(",")))
 # (scratch/stamp_probe.py), the older workgroup of a CU ends after 105 us of a C3 launch, the
 # younger after 145 us, the last 40 us alone on its SIMDs at a third of the pipe rate.
 #   "ab" : priority 1 in the even block of a trip, 0 in the odd one
-PRIO = os.environ.get("GEN_PRIO", "none")
+PRIO = os.environ.get("GEN_PRIO", "turns")
 KS = 4                     # k-steps per block (PK = 32)
 SLOT = KS * 2 * 1024       # bytes of one ring slot
 
@@ -235,7 +230,7 @@ def advance_load_pointers(par):
         f"s_lshl_b32 s{S_T1}, s{S_T0}, 7",
         f"s_add_u32 s{S_T}, s{S_TB}, s{S_T1}",
         f"s_addc_u32 s{S_T + 1}, s{S_TB + 1}, 0",
-        f"s_add_u32 s{S_K}, s{S_K}, 1",
+        f"s_add_u32 s{S_K}, s{S_K}, 2",
     ]
 
 
@@ -307,30 +302,15 @@ def frag_for(label, k2, rh, sp):
     return frag(k2, rh, sp)
 
 
-def iteration(cnt, out, cur, prev, p_cur, p_prev, label):
-    """One block of 32 samples: 48 MFMAs.  cur/prev: C sets; p_cur/p_prev: P registers (4 each)."""
-    out.append(f"; ---- block iteration, C set {label}")
-    if PRIO == "ab":
-        out.append("s_setprio 1" if label == "A" else "s_setprio 0")
-    elif PRIO == "ba":
-        out.append("s_setprio 0" if label == "A" else "s_setprio 1")
-    elif PRIO == "hw":
-        # opposite phases for the two wave slots of a SIMD: slot parity p has priority in its
-        # blocks of parity p
-        want = 0 if label == "A" else 1
-        out.append(f"s_cmp_eq_u32 s{S_PH}, {want}")
-        out.append(f"s_cbranch_scc1 7{label}1f" if False else f"s_cbranch_scc1 {7 if label == 'A' else 8}f")
-        out.append("s_setprio 0")
-        out.append(f"s_branch {5 if label == 'A' else 6}f")
-        out.append(f"{7 if label == 'A' else 8}:")
-        out.append("s_setprio 1")
-        out.append(f"{5 if label == 'A' else 6}:")
-    elif PRIO == "hwstatic":
-        pass
+def iteration(cnt, out, cur, prev, p_cur, p_prev, label, role):
+    """One block of 32 samples: 48 MFMAs.  cur/prev: C sets; p_cur/p_prev: P registers (4 each).
+    role 0 converts in the even block of a trip (label A), role 1 in the odd one (label B)."""
+    conv = (label == "A") == (role == 0)
+    out.append(f"; ---- block iteration, C set {label}, role {role}, conv {conv}")
     rot = rotate_ops(prev, p_prev)
     prod = produce_ops()
     other = "B" if label == "A" else "A"
-    salu = advance_load_pointers(other)          # for the next iteration's loads
+    salu = advance_load_pointers(label) if conv else []   # for this iteration's loads (gap 36)
     S_P, N_P = SB[label]["p"], SB[other]["p"]
     NG = 48
     gaps = {g: [] for g in range(NG)}
@@ -366,24 +346,29 @@ def iteration(cnt, out, cur, prev, p_cur, p_prev, label):
         for _ in range(2):
             gaps[g].append(("rot", rot[ri], None))
             ri += 1
-    # conversion of block b+2: gaps 20..33
-    pi = 0
-    for g in range(20, 34):
-        for _ in range(2):
-            if pi < len(prod):
-                gaps[g].append(("prod", prod[pi], None))
-                pi += 1
-    assert pi == len(prod), (pi, len(prod))
+    # conversion of block b+2 (this wave's turn every other block): gaps 20..33
+    if conv:
+        pi = 0
+        for g in range(20, 34):
+            for _ in range(2):
+                if pi < len(prod):
+                    gaps[g].append(("prod", prod[pi], None))
+                    pi += 1
+        assert pi == len(prod), (pi, len(prod))
     left = len(rot) - ri
     for k in range(left):
-        g = 34 + (k * 14) // left
+        g = (34 + (k * 14) // left) if conv else (20 + (k * 28) // left)
         gaps[g].append(("rot", rot[ri], None))
         ri += 1
     assert ri == len(rot), ri
-    gaps[34].append(("ldsw", f"ds_write_b128 {vr(V_WR)}, {vr(HI4, 4)}", "wh"))
-    gaps[34].append(("ldsw", f"ds_write_b128 {vr(V_WR)}, {vr(LO4, 4)} offset:1024", "wl"))
-    # loads of block b+3 once the conversion has read XA/XB/HV
-    gaps[36].append(("gload", None, None))
+    if conv:
+        gaps[34].append(("ldsw", f"ds_write_b128 {vr(V_WR)}, {vr(HI4, 4)}", "wh"))
+        gaps[34].append(("ldsw", f"ds_write_b128 {vr(V_WR)}, {vr(LO4, 4)} offset:1024", "wl"))
+        # loads of block b+4 once the conversion has read XA/XB/HV
+        gaps[36].append(("gload", None, None))
+    # the partners of a SIMD take the matrix pipe in turns: priority in "their" k-step
+    gaps[0].insert(0, ("prio", f"s_setprio {1 if role == 0 else 0}", None))
+    gaps[24].insert(0, ("prio", f"s_setprio {0 if role == 0 else 1}", None))
     # ring slot rotation and addresses of the next iteration (all ring accesses issued by gap 38)
     gaps[40].append(("salu", f"s_mov_b32 s{S_T0}, s{S_RD}", None))
     gaps[40].append(("salu", f"s_mov_b32 s{S_RD}, s{S_RDN}", None))
@@ -409,6 +394,9 @@ def iteration(cnt, out, cur, prev, p_cur, p_prev, label):
         for kind, text, tag in gaps[g]:
             if kind == "lds" and "lds" in ABLATE:
                 pass
+            elif kind == "prio":
+                if PRIO != "none":
+                    out.append(text)
             elif kind == "lds" or kind == "ldsw":
                 out.append(text)
                 cnt.issue_lgkm(tag)
@@ -437,19 +425,92 @@ def iteration(cnt, out, cur, prev, p_cur, p_prev, label):
         out.append("s_barrier")
 
 
+def role_code(out, role):
+    """Prologue tail, main loop and exits of one role.  Labels are role specific."""
+    o = out.append
+    cnt = Counters(out)
+    L1, L2, L3 = (1, 2, 3) if role == 0 else (11, 12, 13)
+    par = "A" if role == 0 else "B"          # pointer set of this role's loads (conv iteration's label)
+    T1 = (F0, F0 + 4, F0 + 8)                # xa, xb, hv of the second block this role converts
+    # this role converts blocks role, role + 2, ...: load the first two at once (one round trip)
+    o(f"s_mov_b32 s{S_K}, {role}")
+    out.extend(advance_load_pointers(par))
+    o("s_nop 4")
+    gload_ops(cnt, out, par)
+    out.extend(advance_load_pointers("C"))
+    o("s_nop 4")
+    gload_ops(cnt, out, "C", *T1)
+    o("s_waitcnt vmcnt(0)")                  # the phasor images as well
+    cnt.vm = []
+    out.extend(produce_ops(None, None, None))
+    o(f"v_add_u32 {vr(ADDR['B'][0])}, {role * SLOT}, %[wr16]")
+    o(f"ds_write_b128 {vr(ADDR['B'][0])}, {vr(HI4, 4)}")
+    o(f"ds_write_b128 {vr(ADDR['B'][0])}, {vr(LO4, 4)} offset:1024")
+    for i in range(4):
+        o(f"v_mov_b32 {vr(XA + i)}, {vr(T1[0] + i)}")
+        o(f"v_mov_b32 {vr(XB + i)}, {vr(T1[1] + i)}")
+        o(f"v_mov_b32 {vr(HV + i)}, {vr(T1[2] + i)}")
+    V_RD, V_RDN, V_WR = ADDR["A"]
+    o(f"v_add_u32 {vr(V_RD)}, s{S_RD}, %[lane16]")
+    o(f"v_add_u32 {vr(V_RDN)}, s{S_RDN}, %[lane16]")
+    o(f"v_add_u32 {vr(V_WR)}, s{S_WR}, %[wr16]")
+    o("s_waitcnt lgkmcnt(0)")
+    o("s_barrier")
+    for rh in range(2):
+        for sp in range(2):
+            o(f"ds_read_b128 {vr(frag_for('A', 0, rh, sp), 4)}, {vr(V_RD)} offset:{sp * 1024 + rh * 256}")
+    o("s_waitcnt lgkmcnt(0)")
+    cnt.lgkm = []
+
+    def trip(out_, cnt_):
+        iteration(cnt_, out_, CA, CB, PA, PB, "A", role)
+        out_.append(f"s_sub_u32 s{S_NLEFT}, s{S_NLEFT}, 1")
+        out_.append(f"s_cmp_eq_u32 s{S_NLEFT}, 0")
+        out_.append(f"s_cbranch_scc1 {L2}f")
+        iteration(cnt_, out_, CB, CA, PB, PA, "B", role)
+        out_.append(f"s_sub_u32 s{S_NLEFT}, s{S_NLEFT}, 1")
+        out_.append(f"s_cmp_lg_u32 s{S_NLEFT}, 0")
+        out_.append(f"s_cbranch_scc1 {L1}b")
+
+    # outstanding vector-memory operations at the top of a trip in the steady state: found as
+    # the fixed point of one trip (the real first trip has fewer outstanding, which only makes
+    # the counted waits conservative)
+    state = []
+    for _ in range(4):
+        probe = Counters([])
+        probe.vm = list(state)
+        trip(probe.out, probe)
+        assert probe.lgkm == []
+        if probe.vm == state:
+            break
+        state = list(probe.vm)
+    else:
+        raise AssertionError("no steady state")
+    cnt.vm = list(state)
+    o(f"; ===== main loop of role {role}, two blocks per trip; vm at the top: {state}")
+    o(f"{L1}:")
+    trip(out, cnt)
+    assert cnt.lgkm == [] and cnt.vm == state, (cnt.lgkm, cnt.vm, state)
+    # exits: P*C of the last block
+    o("s_waitcnt vmcnt(0)")
+    o("s_nop 15")
+    o("s_nop 15")
+    out.extend(rotate_ops(CB, PB))
+    o(f"s_branch {L3}f")
+    o(f"{L2}:")
+    o("s_waitcnt vmcnt(0)")
+    o("s_nop 15")
+    o("s_nop 15")
+    out.extend(rotate_ops(CA, PA))
+    o(f"{L3}:")
+
+
 def generate():
     out = []
-    cnt = Counters(out)
     o = out.append
     o("; ===== prologue =====")
     o(f"s_mov_b32 s{S_XB}, %[xb_lo]")
     o(f"s_mov_b32 s{S_XB + 1}, %[xb_hi]")
-    if DIRECT:
-        o(f"s_mov_b64 s[{S_EXEC}:{S_EXEC + 1}], exec")
-        o(f"s_mov_b32 s{S_CB}, %[cb_lo]")
-        o(f"s_mov_b32 s{S_CB + 1}, %[cb_hi]")
-        o(f"s_mov_b32 s{S_SMAX}, %[smax]")
-        o(f"s_mov_b32 s{S_CL8}, %[cl8]")
     o(f"s_mov_b32 s{S_TB}, %[tp_lo]")
     o(f"s_mov_b32 s{S_TB + 1}, %[tp_hi]")
     o(f"s_mov_b32 s{SB['A']['p']}, %[pp_lo]")
@@ -459,16 +520,6 @@ def generate():
     o(f"s_mov_b32 s{S_PSTRIDE}, %[pstride]")
     o(f"s_mov_b32 s{S_NLEFT}, %[nhi]")
     o(f"s_add_u32 s{S_NHI1}, %[nhi], -1")
-    o(f"s_mov_b32 s{S_K}, 0")
-    if PRIO in ("hw", "hwstatic"):
-        o(f"s_getreg_b32 s{S_PH}, hwreg(HW_REG_HW_ID, 0, 4)")
-        o(f"s_and_b32 s{S_PH}, s{S_PH}, 1")
-    if PRIO == "hwstatic":
-        # the wave in the odd slot of its SIMD (the later arrival) takes priority for good
-        o(f"s_cmp_eq_u32 s{S_PH}, 1")
-        o("s_cbranch_scc0 9f")
-        o("s_setprio 1")
-        o("9:")
     o(f"v_mov_b32 {vr(V_SC)}, %[scale]")
     o(f"s_mov_b32 s{S_RD}, 0")
     o(f"s_mov_b32 s{S_RDN}, {SLOT}")
@@ -481,100 +532,24 @@ def generate():
         o(f"s_add_u32 s{BF[j]}, s{S_BF}, {4096 * j}")
         o(f"s_addc_u32 s{BF[j] + 1}, s{S_BF + 1}, 0")
     o("s_nop 4")
-    # (a workgroup that runs the loop for a second row tile keeps them: %[first] == 0)
-    if not DIRECT:
-        o("s_cmp_eq_u32 %[first], 0")
-        o("s_cbranch_scc1 4f")
     for f in range(16):
         b = BF[f // 4]
         if "bimg" not in ABLATE:
             o(f"global_load_dwordx4 {ar(4 * f)}, %[bo], s[{b}:{b + 1}] offset:{(f % 4) * 1024}")
-    if not DIRECT:
-        o("4:")
     # zero: C set B, accumulators, P_B
     for base in (CB[0], CB[1], ACC[0], ACC[1]):
         for i in range(16):
             o(f"v_mov_b32 {vr(base + i)}, 0")
     for i in range(4):
         o(f"v_mov_b32 {vr(PB + i)}, 0")
-    # blocks 0, 1 and 2 are loaded at once (one round trip): block 0 into the input
-    # registers, 1 and 2 into the still idle operand buffers; 0 and 1 are converted
-    # into ring slots 0 and 1, block 2 is moved to the input registers for trip 0
-    T1 = (F0, F0 + 4, F0 + 8)          # xa, xb, hv of block 1
-    T2 = (F0 + 12, F0 + 16, F0 + 20)   # of block 2
-    OFF_C = (CA[0], CA[0] + 1)          # offsets of block 2: set A is written by the first MFMA only
-    out.extend(advance_load_pointers("A"))
-    if DIRECT:
-        out.extend(offset_ops("A"))
-    out.extend(advance_load_pointers("B"))
-    if DIRECT:
-        out.extend(offset_ops("B"))
-    out.extend(advance_load_pointers("C"))
-    if DIRECT:
-        out.extend(offset_ops("C", OFF_C))
-    o("s_nop 4")
-    gload_ops(cnt, out, "A")
-    gload_ops(cnt, out, "B", *T1)
-    gload_ops(cnt, out, "C", *T2, off=OFF_C)
-    o("s_waitcnt vmcnt(0)")          # the phasor images as well
-    cnt.vm = []
-    for blk, src in ((0, (None, None, None)), (1, T1)):
-        out.extend(produce_ops(*src))
-        o(f"v_add_u32 {vr(ADDR['B'][blk])}, {blk * SLOT}, %[wr16]")
-        o(f"ds_write_b128 {vr(ADDR['B'][blk])}, {vr(HI4, 4)}")
-        o(f"ds_write_b128 {vr(ADDR['B'][blk])}, {vr(LO4, 4)} offset:1024")
-        o("s_waitcnt lgkmcnt(0)")
-    for i in range(4):
-        o(f"v_mov_b32 {vr(XA + i)}, {vr(T2[0] + i)}")
-        o(f"v_mov_b32 {vr(XB + i)}, {vr(T2[1] + i)}")
-        o(f"v_mov_b32 {vr(HV + i)}, {vr(T2[2] + i)}")
-    out.extend(advance_load_pointers("A"))   # block 3: iteration 0 ("A") loads it
-    if DIRECT:
-        out.extend(offset_ops("A"))
-    V_RD, V_RDN, V_WR = ADDR["A"]
-    o(f"v_add_u32 {vr(V_RD)}, s{S_RD}, %[lane16]")
-    o(f"v_add_u32 {vr(V_RDN)}, s{S_RDN}, %[lane16]")
-    o(f"v_add_u32 {vr(V_WR)}, s{S_WR}, %[wr16]")
-    o("s_waitcnt lgkmcnt(0)")
-    o("s_barrier")
-    for rh in range(2):
-        for sp in range(2):
-            o(f"ds_read_b128 {vr(frag_for('A', 0, rh, sp), 4)}, {vr(V_RD)} offset:{sp * 1024 + rh * 256}")
-    o("s_waitcnt lgkmcnt(0)")
-    cnt.lgkm = []
-    # steady state entry: vm = [hv, xa, xb]; the loop expects [p_prev, hv, xa, xb]
-    XL = ["hv", "xa", "xb", "xa", "xb"] if DIRECT else ["hv", "xa", "xb"]
-    cnt.vm = ["prB", "pB"] + XL
-    o("; ===== main loop, two blocks per trip =====")
-    o("1:")
-    iteration(cnt, out, CA, CB, PA, PB, "A")
-    o(f"s_sub_u32 s{S_NLEFT}, s{S_NLEFT}, 1")
-    o(f"s_cmp_eq_u32 s{S_NLEFT}, 0")
-    o("s_cbranch_scc1 2f")
-    state_a = (list(cnt.lgkm), list(cnt.vm))
-    iteration(cnt, out, CB, CA, PB, PA, "B")
-    o(f"s_sub_u32 s{S_NLEFT}, s{S_NLEFT}, 1")
-    o(f"s_cmp_lg_u32 s{S_NLEFT}, 0")
-    o("s_cbranch_scc1 1b")
-    if "gload" not in ABLATE:
-        assert cnt.lgkm == [] and cnt.vm == ["prB", "pB"] + XL, (cnt.lgkm, cnt.vm)
-        assert state_a == ([], ["prA", "pA"] + XL), state_a
-    # exits: P*C of the last block
-    o("; last block was in set B")
-    o("s_waitcnt vmcnt(0)")
-    o("s_nop 15")
-    o("s_nop 15")
-    out.extend(rotate_ops(CB, PB))
-    o("s_branch 3f")
-    o("2:")
-    o("; last block was in set A")
-
-
-    o("s_waitcnt vmcnt(0)")
-    o("s_nop 15")
-    o("s_nop 15")
-    out.extend(rotate_ops(CA, PA))
-    o("3:")
+    o("s_cmp_eq_u32 %[role], 0")
+    o("s_cbranch_scc0 20f")
+    role_code(out, 0)
+    o("s_branch 30f")
+    o("20:")
+    role_code(out, 1)
+    o("30:")
+    o("s_setprio 0")
     # hand the accumulators to the C++ epilogue through LDS (the ring is idle: every
     # wave passed the barrier that ended the last iteration)
     for q in range(8):
@@ -586,9 +561,9 @@ def generate():
 
 def main():
     lines = generate()
-    PFX = "GSDR_MFMA_RING16"
-    print("// GENERATED by tools/gen_ddc_mfma_ring16.py -- do not edit.")
-    print("// Main loop of ddc_mfma_ring16_kernel (v_mfma_f32_16x16x32_f16): see the generator for the schedule and register map.")
+    PFX = "GSDR_MFMA_RING16W8"
+    print("// GENERATED by tools/gen_ddc_mfma_ring16w8.py -- do not edit.")
+    print("// Main loop of ddc_mfma_ring16w8_kernel (8 waves per workgroup, v_mfma_f32_16x16x32_f16): see the generator for the schedule and register map.")
     print("#pragma once")
     print(f"#define {PFX}_VB {VB}")
     print(f"#define {PFX}_BYTES {3 * SLOT}")
