@@ -370,10 +370,12 @@ int setup_mfma(gsdr_demod *h, bool direct, const std::vector<long long> &tone) {
     h->mf_W = env_int("GSDR_MFMA_W", 4);
     if (h->mf_W != 2 && h->mf_W != 4) h->mf_W = 4;
     if (h->mf_W > h->mf_PK / 8) h->mf_W = h->mf_PK / 8;   // every wave converts whole k-steps
-    // the assembly main loops exist for the default shape only; GSDR_MFMA_ASM: 2 = LDS operand
-    // ring (default), 1 = ring-less loop (needs the scaled taps in its 40 KiB LDS table:
-    // 10240 - 128 taps), 0 = the compiler-scheduled kernel (A/B runs, tests)
-    const int asm_kind = env_int("GSDR_MFMA_ASM", 2);
+    // the assembly main loops exist for the default shape only; GSDR_MFMA_ASM: 4 = LDS operand ring
+    // on v_mfma_f32_16x16x32_f16 (default since round 2: the same cycles per FLOP for less energy,
+    // +7 % on C3 under the power cap), 5 = that loop for workgroups of eight waves, 2 = the ring on
+    // v_mfma_f32_32x32x16_f16 (round 1's production kernel), 1 = ring-less loop (needs the scaled
+    // taps in its 40 KiB LDS table: 10240 - 128 taps), 0 = the compiler-scheduled kernel (A/B runs, tests)
+    const int asm_kind = env_int("GSDR_MFMA_ASM", 4);
     const bool asm_shape = h->mf_TT == 1 && h->mf_PK == 32 && h->mf_W == 4;
     h->mf_kind = gsdr::MfmaKernel::Cxx;
     if (asm_kind == 2 && asm_shape) h->mf_kind = gsdr::MfmaKernel::AsmRing;

@@ -791,8 +791,9 @@ def test_pipelined_submit_wait_equals_process(cuda_device, gsdr_lib, engine):
         b.close()
 
 
+@pytest.mark.parametrize("asm", ["2", "4"], ids=["ring", "ring16"])
 @pytest.mark.parametrize("mode", ["direct", "tones"])
-def test_mixed_entries_and_streams_keep_the_stream_state_in_order(cuda_device, gsdr_lib, monkeypatch, mode):
+def test_mixed_entries_and_streams_keep_the_stream_state_in_order(cuda_device, gsdr_lib, monkeypatch, mode, asm):
     """The FIR carry, the scale slots, the raw windows and the head/tail copies pass from call
     to call ON THE DEVICE.  Calls that arrive on different streams -- process_device on two
     user streams, submit_device in between, with buffers outstanding -- must still see their
@@ -801,7 +802,7 @@ def test_mixed_entries_and_streams_keep_the_stream_state_in_order(cuda_device, g
     wait shows as wrong first rows.  Bit-equal to the same buffers through one in-order stream."""
     import torch
     monkeypatch.setenv("GSDR_DDC_MFMA", "1")
-    monkeypatch.setenv("GSDR_MFMA_ASM", "2")
+    monkeypatch.setenv("GSDR_MFMA_ASM", asm)
     rng = np.random.default_rng(2718)
     if mode == "direct":
         N, rate, M, F, L = 96, 10_000_000, 100, 4, 100_000
@@ -849,9 +850,10 @@ def test_mixed_entries_and_streams_keep_the_stream_state_in_order(cuda_device, g
     b.close()
 
 
+@pytest.mark.parametrize("asm", ["2", "4"], ids=["ring", "ring16"])
 @pytest.mark.parametrize("overlap,streams", [("1", "2"), ("1", "3"), ("0", "2")])
 def test_pipelined_submit_device_overlapping_buffers(cuda_device, gsdr_lib, oracle_mod, monkeypatch, overlap,
-                                                     streams):
+                                                     streams, asm):
     """gsdr_demod_submit_device: the main kernels of consecutive DIRECT buffers run on two
     streams and overlap (the staging passes stay in order).  Buffers of very different
     loudness follow each other, so a kernel that picked up its neighbour's scale slot, head
@@ -859,14 +861,14 @@ def test_pipelined_submit_device_overlapping_buffers(cuda_device, gsdr_lib, orac
     of the oracle."""
     import torch
     monkeypatch.setenv("GSDR_DDC_MFMA", "1")
-    monkeypatch.setenv("GSDR_MFMA_ASM", "2")
+    monkeypatch.setenv("GSDR_MFMA_ASM", asm)
     monkeypatch.setenv("GSDR_PIPE_OVERLAP", overlap)
     monkeypatch.setenv("GSDR_PIPE_STREAMS", streams)
     N, rate, M, F, L = 256, 10_000_000, 100, 4, 200_000
     rng = np.random.default_rng(314)
     freq = rng.choice(np.arange(-rate // 2 + 1, rate // 2), size=N, replace=False)
     a, b = make_direct(freq, rate, M, F, L), make_direct(freq, rate, M, F, L)
-    assert b.kernel_name == "ddc_mfma_ring_kernel"
+    assert b.kernel_name == ("ddc_mfma_ring_kernel" if asm == "2" else "ddc_mfma_ring16_kernel")
     ref = oracle_mod.Direct(freq, rate, M, F, L)
     scales = [1.0, 1e-4, 30.0, 1.0, 1e-3, 1e-3, 100.0, 1.0, 1.0, 1e-2, 5.0]
     xs = [torch.from_numpy((crandn(rng, L) * np.float32(sc)).astype(np.complex64)).to(cuda_device) for sc in scales]
