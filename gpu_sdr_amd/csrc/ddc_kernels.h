@@ -120,6 +120,25 @@ enum class MfmaKernel { AsmRing, AsmSolo, Cxx, AsmRingDirect, AsmRing16, AsmRing
 hipError_t launch_ddc_mfma(MfmaKernel kind, int TT, int PK, int W, const MfmaLaunch &a, hipStream_t st);
 const char *ddc_mfma_kernel_name(MfmaKernel kind);
 
+// ---- batched FFT of arbitrary length + polyphase filter (NOISE mode, fft_kernels.hip) ----
+struct FftPlan {
+    int n = 0;                 // transform length
+    int m = 0;                 // 0: mixed-radix Stockham stages over n; else Bluestein through length m = 2^k
+    int n_radices = 0;
+    int radices[32] = {};      // stages of n (m == 0) or of m
+    float2 *d_tw = nullptr;    // w_len^k, len = n or m
+    float2 *d_chirp = nullptr; // Bluestein: exp(+i pi k^2 / n), k < n
+    float2 *d_bhat = nullptr;  // Bluestein: transform of the wrapped chirp, length m
+};
+int fft_plan_build(FftPlan &pl, int n);
+void fft_plan_free(FftPlan &pl);
+// [batch][n] in src -> [batch][n] in dst; src and tmp are scratch of batch * max(n, m) each (src is destroyed)
+hipError_t fft_forward(const FftPlan &pl, float2 *src, float2 *dst, float2 *tmp, int batch, hipStream_t st);
+// frames[r][k] = sum_{i<avg} raw[(r+i)*nfft + k] * window[i*nfft + k], r < frames_n (ref: cpp/kernels.cu:474-516)
+hipError_t launch_pfb_filter(const float2 *raw, const float *window, int nfft, int avg, int frames_n, float2 *frames,
+                             hipStream_t st);
+const char *fft_kernel_name();
+
 // ---- chirp ---------------------------------------------------------------
 struct ChirpShape {
     unsigned long long num_steps, length, period;  // period = num_steps*length

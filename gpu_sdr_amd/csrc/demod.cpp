@@ -137,6 +137,11 @@ struct gsdr_demod {
     float2 *d_win[kStageSets] = {};
     unsigned long long win_seq = 0;    // TONES/NOISE calls so far
     long long prev_spare_begin = 0, prev_spare_samples = 0;
+    // ---- NOISE through the FFT stage (fft_kernels.hip) ----
+    bool noise_fft = false;
+    gsdr::FftPlan fft{};
+    float2 *d_fft_a = nullptr, *d_fft_b = nullptr;   // frames / scratch, batching * max(nfft, m) each
+    float *d_fft_win = nullptr;                      // the PFB window on the device
     // ---- CHIRP ----
     ChirpShape cs{};
     int ppt = 0;
@@ -727,8 +732,34 @@ int enqueue_direct(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t st)
     return (int)ret;
 }
 
+// ref: process_pfb_spec (decim == 0), cpp/USRP_demodulator.cpp:568-649: polyphase filter, forward FFT of
+// every complete frame, all bins kept.  Frame bookkeeping and the carry of the unconsumed samples
+// are those of enqueue_pfb (the raw windows rotate, see there).
+int enqueue_noise_fft(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t st) {
+    const int cb = h->bh.current_batch;
+    float2 *win = h->d_win[h->win_seq % kStageSets];
+    if (h->prev_spare_samples > 0)   // :590-596 of the previous call
+        HIPCHK(h, hipMemcpyAsync(win, h->d_win[(h->win_seq + kStageSets - 1) % kStageSets] + h->prev_spare_begin,
+                                 (size_t)h->prev_spare_samples * sizeof(float2), hipMemcpyDeviceToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(win + h->bh.new_0, in, (size_t)h->L * sizeof(float2), hipMemcpyDeviceToDevice, st));  // :573-577
+    if (cb > 0) {
+        hipEvent_t stop = nullptr;
+        if (record_begin(h, st, &stop)) return -1;
+        HIPCHK(h, gsdr::launch_pfb_filter(win, h->d_fft_win, h->nfft, h->F, cb, h->d_fft_a, st));   // :580
+        HIPCHK(h, gsdr::fft_forward(h->fft, h->d_fft_a, out, h->d_fft_b, cb, st));                   // :583
+        if (stop) HIPCHK(h, hipEventRecord(stop, st));
+    }
+    h->prev_spare_begin = h->bh.spare_begin;
+    h->prev_spare_samples = h->bh.spare_samples > 0 ? h->bh.spare_samples : 0;
+    h->win_seq++;
+    const int ret = h->nfft * cb;        // copy_size :638
+    gsdr_buffer_helper_update(&h->bh);   // :644
+    return ret;
+}
+
 // ref: process_pfb (decim == 0 branch), cpp/USRP_demodulator.cpp:486-565
 int enqueue_pfb(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t st) {
+    if (h->noise_fft) return enqueue_noise_fft(h, in, out, st);
     // :491-495  new buffer goes after the carried samples
     const int cb = h->bh.current_batch;
     float2 *win = h->d_win[h->win_seq % kStageSets];
@@ -962,10 +993,12 @@ gsdr_demod *gsdr_demod_create(const gsdr_param_c *p) {
                       "TONES/NOISE with decim > 0 is not supported: the reference path is broken "
                       "(ref: kernels.cu:718-719,747,779, USRP_demodulator.cpp:172,516)")) return nullptr;
             if (!need((long long)p->fft_tones * p->pf_average <= 0x7fffffffLL, "fft_tones*pf_average overflows")) return nullptr;
-            // NOISE evaluates all nfft bins with the DDC kernel (O(nfft) per sample, no FFT):
-            // fine for the bin counts the client uses for spectra, refused beyond
-            if (!need(!noise || p->fft_tones <= 16384,
-                      "NOISE supports fft_tones <= 16384 in this build (direct evaluation of every bin)")) return nullptr;
+            // NOISE: polyphase filter + batched FFT of every frame (fft_kernels.hip), any fft_tones.
+            // GSDR_NOISE_FFT=0 evaluates every bin as a DDC tone instead (round 1's path: O(fft_tones)
+            // per sample, kept for A/B runs and refused above 16384 bins)
+            const bool noise_fft = noise && env_int("GSDR_NOISE_FFT", 1) != 0;
+            if (!need(!noise || noise_fft || p->fft_tones <= 16384,
+                      "NOISE without the FFT stage (GSDR_NOISE_FFT=0) supports fft_tones <= 16384")) return nullptr;
             h->nfft = p->fft_tones;
             const int F = (int)p->pf_average;
             h->fcut = (float)(1. / (2 * h->nfft));                     // :131, :274
@@ -984,6 +1017,23 @@ gsdr_demod *gsdr_demod_create(const gsdr_param_c *p) {
             // buffer_helper(n_tones, buffer_len, average, n_eff_tones): :159 / :301
             gsdr_buffer_helper_init(&h->bh, h->nfft, (int)h->L, F, n_ch);
             h->ddc_channels = n_ch;
+            if (noise_fft) {
+                h->noise_fft = true;
+                h->F = F;
+                h->M = h->nfft;
+                h->kernel_name = gsdr::fft_kernel_name();
+                if (!need(gsdr::fft_plan_build(h->fft, h->nfft) == 0, "cannot plan an FFT of fft_tones points")) return nullptr;
+                const size_t len = (size_t)(h->fft.m > h->nfft ? h->fft.m : h->nfft) * (size_t)h->batching;
+                const size_t nwin = (size_t)h->nfft * h->batching * 2;
+                bool ok = dev_alloc(&h->d_fft_a, len) == hipSuccess && dev_alloc(&h->d_fft_b, len) == hipSuccess &&
+                          upload(&h->d_fft_win, h->window) == hipSuccess;
+                for (int i = 0; i < kStageSets && ok; ++i)
+                    ok = dev_alloc(&h->d_win[i], nwin) == hipSuccess &&
+                         hipMemset(h->d_win[i], 0, nwin * sizeof(float2)) == hipSuccess;
+                if (!need(ok, "NOISE allocation failed")) return nullptr;
+                h->capacity = (long long)n_ch * h->batching;               // :288
+                break;
+            }
             rc = setup_ddc_common(h, F, h->nfft, (unsigned)h->nfft, tone,
                                   (int)(h->L / h->nfft) + F + 6);
             h->kernel_name = h->pipe ? gsdr::ddc_flat_kernel_name() : gsdr::ddc_kernel_name();
@@ -1371,6 +1421,10 @@ void gsdr_demod_close(gsdr_demod *h) {
         if (h->d_head[i]) (void)hipFree(h->d_head[i]);
         if (h->d_tail[i]) (void)hipFree(h->d_tail[i]);
     }
+    gsdr::fft_plan_free(h->fft);
+    if (h->d_fft_a) (void)hipFree(h->d_fft_a);
+    if (h->d_fft_b) (void)hipFree(h->d_fft_b);
+    if (h->d_fft_win) (void)hipFree(h->d_fft_win);
     if (h->stream) (void)hipStreamDestroy(h->stream);  // ref: 03_implement.md:58-63
     delete h;
 }
@@ -1440,7 +1494,7 @@ int gsdr_demod_describe(const gsdr_demod *h, char *buf, int cap) {
     s += "\", \"kernel\": \"";
     s += h->kernel_name;
     s += "\", \"family\": \"";
-    s += h->mfma ? "f16 MFMA, hi/lo split" : (h->mode == GSDR_CHIRP ? "fp32 VALU, integer phase" : (h->pipe ? "packed fp32 VALU" : "fp32 VALU"));
+    s += h->noise_fft ? "fp32 Stockham FFT behind the polyphase filter" : h->mfma ? "f16 MFMA, hi/lo split" : (h->mode == GSDR_CHIRP ? "fp32 VALU, integer phase" : (h->pipe ? "packed fp32 VALU" : "fp32 VALU"));
     s += "\", \"channels\": " + std::to_string(h->ddc_channels > 0 ? h->ddc_channels : h->N);
     s += ", \"row_tiles_per_workgroup\": " + std::to_string(h->mfma ? h->last_rt : 0);
     s += ", \"pipeline_streams\": " + std::to_string(h->pipe_ready ? h->pipe_streams : env_int("GSDR_PIPE_STREAMS", kPipeStreams));

@@ -531,9 +531,12 @@ def test_pfb_parity(cuda_device, gsdr_lib, oracle_mod, case, engine):
 
 @pytest.mark.parametrize("nfft,avg,L,nbuf", [(16, 3, 200, 4), (100, 4, 50_000, 3), (1000, 4, 50_123, 3),
                                             (64, 1, 4096, 2)])
-def test_noise_full_spectrum_parity(cuda_device, gsdr_lib, oracle_mod, nfft, avg, L, nbuf, engine):
-    """NOISE, decim == 0 (ref: process_pfb_spec): every FFT bin, [frame][bin]."""
+def test_noise_full_spectrum_parity(cuda_device, gsdr_lib, oracle_mod, monkeypatch, nfft, avg, L, nbuf, engine):
+    """NOISE, decim == 0 (ref: process_pfb_spec): every FFT bin, [frame][bin].  This is round 1's
+    evaluation of every bin as a DDC tone (GSDR_NOISE_FFT=0), once per DDC engine; the FFT stage
+    that NOISE uses by default has its own cases below."""
     import gpu_sdr_amd as g
+    monkeypatch.setenv("GSDR_NOISE_FFT", "0")
     rng = np.random.default_rng(4000 + nfft)
     p = g.param(mode="RX", rate=1_000_000, buffer_len=L, decim=0, pf_average=avg, fft_tones=nfft,
                 freq=[0], wave_type=[g.w_type.NOISE])
@@ -549,6 +552,82 @@ def test_noise_full_spectrum_parity(cuda_device, gsdr_lib, oracle_mod, nfft, avg
         if yr.size:
             assert rel_err_per_tone(y.reshape(-1, nfft), yr).max() <= TOL
     dem.close()
+
+
+NOISE_FFT_CASES = [
+    # nfft, avg, L, buffers                      stages
+    (16, 3, 200, 4),                           # 4 4
+    (64, 1, 4096, 2),                          # 4 4 4, no averaging
+    (100, 4, 50_000, 3),                       # 4 5 5
+    (1000, 4, 50_123, 3),                      # 4 2 5 5 5, L not a multiple of nfft
+    (1230, 4, 100_000, 3),                     # 2 3 5 41: prime factor 41 -> Bluestein through 4096
+    (2 * 3 * 5 * 7 * 11 * 13, 2, 200_000, 2),  # 30030: every generic butterfly
+    (1, 2, 100, 2),                            # degenerate: the "FFT" of one point
+    (2, 4, 50_000, 2),
+    (4099, 3, 60_000, 3),                      # prime: Bluestein through 16384
+    (8192, 4, 100_000, 2),                     # 4^6 * 2
+]
+
+
+@pytest.mark.parametrize("nfft,avg,L,nbuf", NOISE_FFT_CASES, ids=lambda v: str(v))
+def test_noise_fft_stage_parity(cuda_device, gsdr_lib, oracle_mod, nfft, avg, L, nbuf):
+    """NOISE through the hand-written FFT stage (csrc/fft_kernels.hip): polyphase filter, then a
+    batched forward FFT of every complete frame -- mixed-radix Stockham stages, Bluestein for
+    lengths with a prime factor above 13 -- against the oracle's fp64 DFT of every bin.  Frame
+    counts per call and the carry of unconsumed samples are exact."""
+    import gpu_sdr_amd as g
+    rng = np.random.default_rng(4100 + nfft)
+    p = g.param(mode="RX", rate=1_000_000, buffer_len=L, decim=0, pf_average=avg, fft_tones=nfft,
+                freq=[0], wave_type=[g.w_type.NOISE])
+    dem = g.RX_buffer_demodulator(p, device_index=0)
+    assert dem.kernel_name == "fft_pass_kernel"
+    ref = oracle_mod.Noise(nfft, avg, L)
+    assert dem.out_capacity == nfft * ref.batching
+    for c in range(nbuf):
+        x = crandn(rng, L)
+        y = (run_host if c % 2 else run_device)(dem, x, *(() if c % 2 else (cuda_device,)))
+        yr = ref.process(x)
+        assert y.size == yr.size, (c, y.size, yr.size)
+        if yr.size:
+            # per bin over the frames of the call, and over everything together (few frames per
+            # call at large nfft make a single bin's norm small)
+            e_all = float(np.linalg.norm(y.reshape(-1, nfft) - yr) / np.linalg.norm(yr))
+            record_margin(e_all, "all bins together")
+            assert e_all <= TOL
+            if yr.shape[0] >= 8:
+                assert rel_err_per_tone(y.reshape(-1, nfft), yr).max() <= TOL
+    dem.close()
+
+
+def test_noise_beyond_16384_bins(cuda_device, gsdr_lib):
+    """fft_tones > 16384 (refused in round 1, where every bin was a DDC tone): 20000 = 4^2 2 5^4
+    and 65536 bins, 1 M-sample buffers, against numpy's double-precision FFT of the same
+    polyphase-filtered frames (the oracle's O(nfft^2) DFT would take minutes here)."""
+    import gpu_sdr_amd as g
+    for nfft, avg in ((20_000, 4), (65_536, 2), (17_389, 2)):   # 17389 is prime: Bluestein through 65536
+        L = 1_000_000
+        rng = np.random.default_rng(nfft)
+        p = g.param(mode="RX", rate=200_000_000, buffer_len=L, decim=0, pf_average=avg, fft_tones=nfft,
+                    freq=[0], wave_type=[g.w_type.NOISE])
+        dem = g.RX_buffer_demodulator(p, device_index=0)
+        w = dem.window().astype(np.float64)
+        stream = np.zeros(0, dtype=np.complex64)
+        for c in range(2):
+            x = crandn(rng, L)
+            y = run_device(dem, x, cuda_device).reshape(-1, nfft)
+            stream = np.concatenate([stream, x])
+            # frames r with (r + avg) * nfft < len(stream), as buffer_helper counts them
+            nfr = len([r for r in range(len(stream) // nfft + 1) if r * nfft + avg * nfft < len(stream)])
+            assert y.shape[0] == nfr, (nfft, c, y.shape, nfr)
+            fr = np.zeros((nfr, nfft), dtype=np.complex128)
+            for i in range(avg):
+                fr += stream[i * nfft:(i + nfr) * nfft].astype(np.complex128).reshape(nfr, nfft) * w[i * nfft:(i + 1) * nfft]
+            yr = np.fft.fft(fr, axis=1)
+            e = float(np.linalg.norm(y - yr) / np.linalg.norm(yr))
+            record_margin(e, f"nfft {nfft}")
+            assert e <= TOL, (nfft, c, e)
+            stream = stream[nfr * nfft:]          # the unconsumed samples carry over
+        dem.close()
 
 
 # ---------------------------------------------------------------------------
