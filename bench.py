@@ -565,6 +565,9 @@ def main(argv=None, engine=None):
                     help="the K steps are repeated until the timed region is at least this long")
     ap.add_argument("--no-extras", action="store_true", help="skip the C2 / PFB / chirp / max-tone extras")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baselines")
+    ap.add_argument("--no-host-api", action="store_true",
+                    help="skip the host-pointer (PCIe-inclusive) rates: profiling runs want the traced kernels to be "
+                         "those of the timed entry only")
     ap.add_argument("--ablation", action="store_true",
                     help="allow a timing-only ablation build (GSDR_LIB / -DGSDR_TIMING_BUILD); the line is marked invalid")
     args = ap.parse_args(argv)
@@ -650,7 +653,7 @@ def main(argv=None, engine=None):
         line["INVALID"] = f"timing-only ablation build or switches ({timing_env or build_info}): not a benchmark"
 
     if world == 1 and rank == 0 and not stub:
-        ha = host_api_rates(wl, device, seed)
+        ha = None if args.no_host_api else host_api_rates(wl, device, seed)
         if ha:
             line["host_api"] = ha
         if not args.no_extras:

@@ -1,0 +1,18 @@
+#!/bin/bash
+# round-2 profiles: rocprofv3 kernel-trace stats of the in-order entry (the roofline's kernel duration)
+# and of the default (overlapped) command, plus separate --pmc passes (kernel alone: dispatches serialised)
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+for WL in ${WLS:-c3 c2 pfb c4}; do
+  OUT=$R/gpurun_out/prof_$WL; IO=$R/gpurun_out/prof_${WL}_io
+  mkdir -p $OUT $IO
+  B="$R/bench.py --workload $WL --no-extras --no-cpu --no-host-api --steps 200 --warmup 20 --min-seconds 0.2"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $IO/trace -- python3 $B --api inorder > $IO/trace.log 2>&1 || true
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $B > $OUT/trace.log 2>&1 || true
+  P="$R/bench.py --workload $WL --api inorder --no-extras --no-cpu --no-host-api --steps 30 --warmup 5 --min-seconds 0.01"
+  rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc1 -- python3 $P > $OUT/pmc1.log 2>&1 || true
+  rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM --output-format csv -d $OUT/pmc2 -- python3 $P > $OUT/pmc2.log 2>&1 || true
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc3 -- python3 $P > $OUT/pmc3.log 2>&1 || true
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc4 -- python3 $P > $OUT/pmc4.log 2>&1 || true
+  echo "prof $WL done"
+done

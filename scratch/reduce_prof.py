@@ -1,9 +1,9 @@
-"""Reduces gpurun_out/prof_<wl>/ (scratch/prof.sh) to the files committed under profiles/."""
+"""Reduces gpurun_out/prof_<wl>/ and prof_<wl>_io/ (scratch/prof_r02.sh) to the files committed under profiles/."""
 import collections, csv, glob, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "profiles")
-TAG = "r01"
+TAG = "r02"
 
 
 def newest(pattern):
@@ -57,7 +57,7 @@ def pmc(src_dir, dst):
 
 
 traffic = {}
-for wl, dom in (("c2", "ddc_mfma_ring_kernel"), ("c3", "ddc_mfma_ring_kernel"), ("pfb", "ddc_mfma_ring_kernel"),
+for wl, dom in (("c2", "ddc_mfma_ring16_kernel"), ("c3", "ddc_mfma_ring16_kernel"), ("pfb", "ddc_mfma_ring16_kernel"),
                 ("c4", "chirp_lockin_kernel")):
     src = os.path.join(ROOT, "gpurun_out", "prof_" + wl)
     if not os.path.isdir(src):
