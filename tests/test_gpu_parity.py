@@ -1260,7 +1260,7 @@ def test_nodsp_passthrough(cuda_device, gsdr_lib):
     dem.close()
 
 
-def test_unsupported_requests_fail_loudly(cuda_device, gsdr_lib):
+def test_unsupported_requests_fail_loudly(cuda_device, gsdr_lib, monkeypatch):
     import gpu_sdr_amd as g
     base = dict(rate=1_000_000, buffer_len=1000, freq=[1, 2])
     with pytest.raises(g.GsdrError, match="not supported"):
@@ -1269,8 +1269,13 @@ def test_unsupported_requests_fail_loudly(cuda_device, gsdr_lib):
         g.RX_buffer_demodulator(g.param(decim=7, wave_type=[g.w_type.DIRECT] * 2, **base), device_index=0)
     with pytest.raises(g.GsdrError, match="pf_average"):
         g.RX_buffer_demodulator(g.param(decim=10, pf_average=9, wave_type=[g.w_type.DIRECT] * 2, **base), device_index=0)
+    # NOISE takes any fft_tones through the FFT stage; only round 1's bin-by-bin evaluation is bounded
+    g.RX_buffer_demodulator(g.param(fft_tones=20000, wave_type=[g.w_type.NOISE], **dict(base, buffer_len=100_000)),
+                            device_index=0).close()
+    monkeypatch.setenv("GSDR_NOISE_FFT", "0")
     with pytest.raises(g.GsdrError, match="fft_tones <= 16384"):
         g.RX_buffer_demodulator(g.param(fft_tones=20000, wave_type=[g.w_type.NOISE], **base), device_index=0)
+    monkeypatch.delenv("GSDR_NOISE_FFT")
     with pytest.raises(g.GsdrError, match="not supported"):
         g.RX_buffer_demodulator(g.param(decim=2, fft_tones=10, wave_type=[g.w_type.NOISE], **base), device_index=0)
     with pytest.raises(g.GsdrError, match="Void demodulation"):
