@@ -563,6 +563,8 @@ def main(argv=None, engine=None):
                     help="entry the timed steps go through; auto = pipelined for the DDC (DIRECT, TONES) workloads")
     ap.add_argument("--min-seconds", type=float, default=1.0,
                     help="the K steps are repeated until the timed region is at least this long")
+    ap.add_argument("--tones", type=int, default=0,
+                    help="override the workload's tone count (experiments; the line says so in config.tones_per_stream)")
     ap.add_argument("--no-extras", action="store_true", help="skip the C2 / PFB / chirp / max-tone extras")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baselines")
     ap.add_argument("--no-host-api", action="store_true",
@@ -591,6 +593,8 @@ def main(argv=None, engine=None):
         sys.exit(2)
 
     wl = WORKLOADS[args.workload]
+    if args.tones > 0 and "n_tones" in wl:
+        wl = WORKLOADS[args.workload] = dict(wl, n_tones=args.tones, name=wl["name"] + f" [tones overridden: {args.tones}]")
     seed = stream_seed(rank)
     cpu = {}
     if not stub and world == 1 and rank == 0 and not args.no_cpu:

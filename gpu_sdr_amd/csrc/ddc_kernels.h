@@ -95,6 +95,7 @@ struct MfmaLaunch {
     const unsigned *maxbits;   // [slots][16] absmax slots (16 partial maxima each)
     float2 *out;
     float2 *carry_out;         // AsmRingDirect: receives x[nx - carry_len .. nx); `head` is the carry read
+    const uint4 *img;          // AsmRing16P: [ngt][nhi] pre-converted ring-slot images of 8 KiB (ddc_convert_kernel)
     MfmaShape sh;
 };
 
@@ -116,7 +117,7 @@ hipError_t launch_absmax(const float2 *x, long long n, unsigned *slots, int cur,
 // AsmRing: assembly main loop, operand shared through an LDS ring (production);
 // AsmSolo: assembly main loop, every wave converts its own operand; Cxx: compiler-scheduled
 // (TT, PK, W apply to it only; the assembly kernels are TT = 1, PK = 32, W = 4).
-enum class MfmaKernel { AsmRing, AsmSolo, Cxx, AsmRingDirect, AsmRing16, AsmRing16W8 };
+enum class MfmaKernel { AsmRing, AsmSolo, Cxx, AsmRingDirect, AsmRing16, AsmRing16W8, AsmRing16P };
 hipError_t launch_ddc_mfma(MfmaKernel kind, int TT, int PK, int W, const MfmaLaunch &a, hipStream_t st);
 const char *ddc_mfma_kernel_name(MfmaKernel kind);
 

@@ -40,6 +40,7 @@
 #include "ddc_mfma_ring_gen.h"
 #include "ddc_mfma_ring16_gen.h"
 #include "ddc_mfma_ring16w8_gen.h"
+#include "ddc_mfma_ring16p_gen.h"
 #include "ddc_mfma_ringd_gen.h"
 
 namespace gsdr {
@@ -60,6 +61,10 @@ struct Frag {
 
 // one complex sample times its (scaled) tap, split into fp16 hi and lo
 __device__ __forceinline__ void split_pair(float xr, float xi, float hs, half2v &hi, half2v &lo) {
+    // no contraction: the residual is (rounded product) - hi, bit for bit what the assembly loops
+    // compute (v_mul_f32, v_cvt_pk_f16_f32, v_fma_mix_f32 x*1.0 - hi), so that a stream may change
+    // between the kernels that convert in the loop and the pre-converted path from call to call
+#pragma clang fp contract(off)
     const float2v v = {xr * hs, xi * hs};
     hi = __builtin_convertvector(v, half2v);
     const float2v res = v - __builtin_convertvector(hi, float2v);
@@ -824,6 +829,112 @@ __global__ __launch_bounds__(512, 2) __attribute__((target("no-packed-fp32-ops")
     stamp(1);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pre-converted operands (tools/gen_ddc_mfma_ring16p.py).  In a launch of many rounds every
+// workgroup of a row tile -- N/128 of them -- repeats the same loads and the same conversion to
+// build the tone-independent A operand.  ddc_convert_kernel does it ONCE per buffer: one
+// workgroup per (row tile, block) writes the 8-KiB image the ring slot holds (same layout, same
+// arithmetic: make_frag of the compiler-scheduled kernel); ddc_mfma_ring16p_kernel only copies
+// images into its ring by LDS-DMA, three blocks ahead, and spends its vector issue slots on
+// the rotation alone.  Pays from a few thousand tones on (the pass costs ~10 us per buffer).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) __attribute__((target("no-packed-fp32-ops"))) void ddc_convert_kernel(const MfmaLaunch a, uint4 *__restrict__ img, int nhi) {
+    const MfmaShape &sh = a.sh;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int gt = blockIdx.x / nhi, blk = blockIdx.x - gt * nhi;
+    const unsigned mb = slot_max(a.maxbits, sh.slot_cur, sh.slot_prev);
+    int se = 140 - (int)((mb >> 23) & 0xffu);
+    se = se > 100 ? 100 : (se < -100 ? -100 : se);
+    const float S = bits_to_float((unsigned)(127 + se) << 23);
+    const int o = gt * 32 + r;
+    const int oc = o < sh.nout ? o : sh.nout - 1;
+    const float2 *xbase = gt == 0 ? a.head + sh.carry_len : (gt == sh.ngt - 1 ? a.tail - sh.tail0 : a.x);
+    const int k = blk * 4 + wave;       // 8-sample k-step of the window
+    const float4u *px = reinterpret_cast<const float4u *>(xbase + ((long long)(oc + sh.woff) * sh.M + 4 * hh + 8 * k));
+    const float4v xa = px[0], xb = px[1];
+    const float4v hv = *reinterpret_cast<const float4v *>(a.taps + 8 * k + 4 * hh);
+    const Frag f = make_frag(xa, xb, hv * S);
+    uint4 *dst = img + ((size_t)blockIdx.x * 8 + 2 * wave) * 64 + lane;
+    dst[0] = __builtin_bit_cast(uint4, f.hi);
+    dst[64] = __builtin_bit_cast(uint4, f.lo);
+}
+
+__device__ __forceinline__ __attribute__((target("no-packed-fp32-ops"))) void ring16p_tile(
+    const MfmaLaunch &a, uint4 *lds, int gt, int first, int se, int tg, int wave, bool active) {
+    constexpr int KS = 4;
+    const MfmaShape &sh = a.sh;
+    const int Np = sh.NT32 * 32;
+    const int nhi = (sh.nk8 + KS - 1) / KS;
+    unsigned tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = (int)(tid & 63u);
+    const unsigned po = (unsigned)(tg * 32 + (lane & 15)) * 8u;
+    const unsigned bo = (unsigned)tg * (KS * 4 * 1024u) + (unsigned)lane * 16u;
+    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char *)lds;
+    const unsigned rd16 = lds_base + (unsigned)(lane >> 5) * 2048u + (unsigned)(lane & 15) * 16u +
+                          (unsigned)((lane >> 4) & 1) * 512u;
+    // this wave copies the two 1-KiB pieces of old k-step `wave` of every image
+    const unsigned io_hi = (unsigned)wave * 2048u + (unsigned)lane * 16u, io_lo = io_hi + 1024u;
+    const unsigned wrs = lds_base + (unsigned)wave * 2048u;
+    const unsigned accaddr = lds_base + (unsigned)wave * 8192u + (unsigned)lane * 16u;
+    const unsigned long long ibb = (unsigned long long)(a.img + (size_t)gt * nhi * 512), ppb = (unsigned long long)a.ptab,
+                             bfb = (unsigned long long)a.bfrag;
+    asm volatile(GSDR_MFMA_RING16P_TEXT
+                 :
+                 : [io_hi] "v"(io_hi), [io_lo] "v"(io_lo), [po] "v"(po), [bo] "v"(bo), [lane16] "v"(rd16),
+                   [accaddr] "v"(accaddr), [ib_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)ibb)),
+                   [ib_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(ibb >> 32))),
+                   [wrs] "s"(__builtin_amdgcn_readfirstlane((int)wrs)),
+                   [pp_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)ppb)),
+                   [pp_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(ppb >> 32))),
+                   [bf_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)bfb)),
+                   [bf_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(bfb >> 32))),
+                   [pstride] "s"(__builtin_amdgcn_readfirstlane((int)((unsigned)Np * 8u))),
+                   [nhi] "s"(__builtin_amdgcn_readfirstlane(nhi)),
+                   [first] "s"(__builtin_amdgcn_readfirstlane(first))
+                 : GSDR_MFMA_RING16P_CLOBBERS);
+    if (active) {
+        unsigned tid2 = threadIdx.x;
+        asm volatile("" : "+v"(tid2));
+        const int lane2 = (int)(tid2 & 63u);
+        const float invS = bits_to_float((unsigned)(127 - se) << 23) * sh.unscale;
+        float16v accr, acci;
+        const float4v *acc = reinterpret_cast<const float4v *>(lds) + wave * 512 + lane2;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const float4v vr = acc[qd * 64], vi = acc[(qd + 4) * 64];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                accr[qd * 4 + j] = vr[j];
+                acci[qd * 4 + j] = vi[j];
+            }
+        }
+        const int n_self = tg * 32 + (lane2 & 31);
+        store_tile16(a, gt, tg, lane2, invS, tile_phasor(a, gt, a.fmod[n_self]), accr, acci);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops"))) void ddc_mfma_ring16p_kernel(
+    const MfmaLaunch a) {
+    constexpr int W = 4;
+    // ring (4 slots of 8 KiB) while the loop runs, then the accumulators (4 waves x 8 KiB)
+    __shared__ uint4 lds[2048];
+    static_assert(sizeof(uint4) * 2048 >= GSDR_MFMA_RING16P_BYTES, "ring fits");
+    const MfmaShape &sh = a.sh;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int gt0 = (q / sh.ntq) * 8 + xcd;
+    if (gt0 >= sh.ngt) return;
+    const int tg_raw = (q % sh.ntq) * W + wave;
+    const bool active = tg_raw < sh.ntg;
+    const int tg = active ? tg_raw : sh.ntg - 1;
+    const unsigned mb = slot_max(a.maxbits, sh.slot_cur, sh.slot_prev);
+    int se = 140 - (int)((mb >> 23) & 0xffu);
+    se = se > 100 ? 100 : (se < -100 ? -100 : se);
+    ring16p_tile(a, lds, gt0, 1, se, tg, wave, active);
+}
+
 // The ring kernel without its staging pass: ONE launch per buffer.  The loop reads the
 // caller's buffer and the carry directly (tools/gen_ddc_mfma_ring.py --direct: two
 // loads under complementary EXEC masks, clamped at the end of the buffer, where only
@@ -1246,6 +1357,20 @@ hipError_t launch_ddc_mfma(MfmaKernel kind, int TT, int PK, int W, const MfmaLau
         hipLaunchKernelGGL(ddc_mfma_ringd_kernel, dim3((unsigned)grid), dim3(256), 0, st, a);
         return hipGetLastError();
     }
+    if (kind == MfmaKernel::AsmRing16P) {
+        // the conversion pass, then the loop that copies its images (a.img: ngt * nhi images of 8 KiB)
+        if (TT != 1 || PK != 32 || W != 4 || !a.img) return hipErrorInvalidValue;
+        const int nhi = (sh.nk8 + 3) / 4;
+        const long long cgrid = (long long)sh.ngt * nhi;
+        const int gt8 = (sh.ngt + 7) / 8;
+        const long long grid = (long long)gt8 * 8 * sh.ntq;
+        if (cgrid < 1 || cgrid > 0x7fffffffLL || grid < 1 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(ddc_convert_kernel, dim3((unsigned)cgrid), dim3(256), 0, st, a, const_cast<uint4 *>(a.img), nhi);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(ddc_mfma_ring16p_kernel, dim3((unsigned)grid), dim3(256), 0, st, a);
+        return hipGetLastError();
+    }
     if (kind == MfmaKernel::AsmRing16W8) {
         if (TT != 1 || PK != 32 || W != 4) return hipErrorInvalidValue;
         const int gt8 = (sh.ngt + 7) / 8;
@@ -1289,7 +1414,7 @@ hipError_t launch_ddc_mfma(MfmaKernel kind, int TT, int PK, int W, const MfmaLau
 }
 
 const char *ddc_mfma_kernel_name(MfmaKernel kind) {
-    return kind == MfmaKernel::AsmRing16W8 ? "ddc_mfma_ring16w8_kernel" : kind == MfmaKernel::AsmRing16 ? "ddc_mfma_ring16_kernel" : kind == MfmaKernel::AsmRingDirect ? "ddc_mfma_ringd_kernel" : kind == MfmaKernel::AsmRing ? "ddc_mfma_ring_kernel" : kind == MfmaKernel::AsmSolo ? "ddc_mfma_asm_kernel" : "ddc_mfma_kernel";
+    return kind == MfmaKernel::AsmRing16P ? "ddc_mfma_ring16p_kernel" : kind == MfmaKernel::AsmRing16W8 ? "ddc_mfma_ring16w8_kernel" : kind == MfmaKernel::AsmRing16 ? "ddc_mfma_ring16_kernel" : kind == MfmaKernel::AsmRingDirect ? "ddc_mfma_ringd_kernel" : kind == MfmaKernel::AsmRing ? "ddc_mfma_ring_kernel" : kind == MfmaKernel::AsmSolo ? "ddc_mfma_asm_kernel" : "ddc_mfma_kernel";
 }
 
 }  // namespace gsdr

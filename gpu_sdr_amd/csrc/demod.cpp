@@ -105,6 +105,11 @@ struct gsdr_demod {
     gsdr::MfmaShape mf{};              // fields that do not change between calls
     int last_rt = 0;                   // row tiles per workgroup of the last launch (describe())
     bool w8_auto = true;               // GSDR_MFMA_W8: 8-wave workgroups for in-order launches of one round
+    // pre-converted operands (ddc_convert_kernel + ddc_mfma_ring16p_kernel) for launches of many
+    // rounds: one image set per staging set (the main kernels of the calls in flight read theirs)
+    bool prec = false;                 // image sets allocated: the path may be chosen
+    int prec_mode = -1;                // GSDR_MFMA_PREC
+    uint4 *d_img[kStageSets] = {};
     uint4 *d_bfrag = nullptr;
     float2 *d_ptab = nullptr, *d_dtab = nullptr;
     float *d_mtaps = nullptr;
@@ -460,6 +465,26 @@ int setup_mfma(gsdr_demod *h, bool direct, const std::vector<long long> &tone) {
             HIPCHK(h, hipMemset(h->d_tail[i], 0, tail_n * sizeof(float2)));
         }
     }
+    // Pre-converted operands (ddc_convert_kernel + ddc_mfma_ring16p_kernel).
+    // GSDR_MFMA_PREC: 1 = always (tests), 0 = never, default = per launch in enqueue_mfma:
+    //   in-order entries      launches of four rounds of workgroups or more (-9 % at 16 k ... 64 k tones;
+    //                         below that the pass, which runs in front of the loop there, costs more);
+    //   overlapped entries    launches of a full round or more with windows of 32 blocks or more: the
+    //                         pass of buffer j+1 runs beside the loop of buffer j (C3 139 -> 130.5 us per
+    //                         buffer, TONES 1024/1230 76.8 -> 74.0; C2, 13 blocks: neutral, not used).
+    if (h->mf_kind == gsdr::MfmaKernel::AsmRing16) {
+        h->prec_mode = env_int("GSDR_MFMA_PREC", -1);
+        const long long max_rows = direct ? h->L / M : (long long)h->batching;
+        const long long ngt_max = (max_rows + 31) / 32;
+        const long long nhi = (pl.nk8 + 3) / 4;
+        const long long wgs4 = ((ngt_max + 7) / 8) * 8 * sh.ntq;
+        bool want = h->prec_mode == 1 ||
+                    (h->prec_mode < 0 && (wgs4 >= 4LL * (h->simds / 2) || (wgs4 >= h->simds / 2 && nhi >= 32)));
+        const size_t img_n = (size_t)ngt_max * (size_t)nhi * 512;   // uint4 per image set
+        if (want && img_n * sizeof(uint4) > (size_t)8 << 30) want = false;
+        for (int i = 0; i < kStageSets && want; ++i) HIPCHK(h, dev_alloc(&h->d_img[i], img_n));
+        h->prec = want;
+    }
     h->mfma = true;
     h->kernel_name = gsdr::ddc_mfma_kernel_name(h->mf_kind);
     return 0;
@@ -667,7 +692,17 @@ int enqueue_mfma(gsdr_demod *h, const float2 *in, float2 *raw, long long raw_new
     // partners), that kernel ends 4-7 % earlier (C3: 145 against 152-158 us).  The overlapped entries
     // keep the 4-wave kernel: there the next buffer's workgroups fill the slots the older ones free.
     gsdr::MfmaKernel kind = h->mf_kind;
-    if (kind == gsdr::MfmaKernel::AsmRing16 && !h->pipe_overlap && h->w8_auto) {
+    bool use_prec = false;
+    if (kind == gsdr::MfmaKernel::AsmRing16 && h->prec && a.sh.rt <= 1) {
+        const long long wgs4 = (long long)((a.sh.ngt + 7) / 8) * 8 * a.sh.ntq;
+        const int nhi = (a.sh.nk8 + 3) / 4;
+        use_prec = h->prec_mode == 1 || wgs4 >= 4LL * (h->simds / 2) ||
+                   (h->pipe_overlap && wgs4 >= h->simds / 2 && nhi >= 32);
+    }
+    if (use_prec) {
+        kind = gsdr::MfmaKernel::AsmRing16P;
+        a.img = h->d_img[hs];
+    } else if (kind == gsdr::MfmaKernel::AsmRing16 && !h->pipe_overlap && h->w8_auto) {
         const long long wgs4 = (long long)((a.sh.ngt + 7) / 8) * 8 * a.sh.ntq;
         const long long wgs8 = (long long)((a.sh.ngt + 7) / 8) * 8 * ((a.sh.ntg + 7) / 8);
         if (a.sh.rt <= 1 && wgs4 > h->simds / 4 && wgs4 <= h->simds / 2 && wgs8 <= h->simds / 4)
@@ -1433,6 +1468,7 @@ void gsdr_demod_close(gsdr_demod *h) {
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (int i = 0; i < kStageSets; ++i) {
+        if (h->d_img[i]) (void)hipFree(h->d_img[i]);
         if (h->d_win[i]) (void)hipFree(h->d_win[i]);
         if (h->d_head[i]) (void)hipFree(h->d_head[i]);
         if (h->d_tail[i]) (void)hipFree(h->d_tail[i]);

@@ -14,7 +14,7 @@ for v in "$@"; do
 done
 cp /tmp/ab_saved.h $HDR
 for rep in 1 2 3; do for name in "${names[@]}"; do for wl in ${WLS:-c3}; do
-  GSDR_MFMA_ASM=$ASM GSDR_LIB=$PWD/scratch/lib_ab_$name.so python bench.py --ablation --workload $wl --no-extras --no-cpu --steps 200 --warmup 20 --min-seconds ${SECS:-1.5} 2>/dev/null | python -c "
+  GSDR_MFMA_ASM=$ASM GSDR_LIB=$PWD/scratch/lib_ab_$name.so python bench.py --ablation ${BENCH_EXTRA:-} --workload $wl --no-extras --no-cpu --steps 200 --warmup 20 --min-seconds ${SECS:-1.5} 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
 print('rep$rep %-10s $wl pipelined us/step %7.2f  inorder %7.2f  kernel_us %7.2f' % ('$name', d['ms_per_step']*1e3, d['inorder']['ms_per_step']*1e3, r['kernel_us']))"

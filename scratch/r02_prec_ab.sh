@@ -1,0 +1,7 @@
+#!/bin/bash
+for rep in 1 2; do for prec in 0 1; do for tones in ${TONES:-16384 65536}; do
+  GSDR_MFMA_PREC=$prec python bench.py --workload c3 --tones $tones --no-extras --no-cpu --no-host-api --steps ${STEPS:-20} --warmup 3 --min-seconds 1.0 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
+print('rep$rep prec=$prec tones=$tones Msps %8.1f pipelined us/step %9.2f  inorder %9.2f  kernel_us %9.2f %s' % (d['value'], d['ms_per_step']*1e3, d['inorder']['ms_per_step']*1e3, r['kernel_us'], r['kernel']))"
+done; done; done

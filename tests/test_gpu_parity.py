@@ -74,23 +74,25 @@ def make_chirp(rate, f0, f1, steps, t, decim, L):
     return g.RX_buffer_demodulator(p, device_index=0)
 
 
-@pytest.fixture(params=["flat", "mfma", "mfma1", "mfma_rt2", "mfma16", "mfma16w8"])
+@pytest.fixture(params=["flat", "mfma", "mfma1", "mfma_rt2", "mfma16", "mfma16w8", "mfma16p"])
 def engine(request, monkeypatch):
     """Runs a test once per DDC engine: packed-FP32 VALU kernel, matrix-core kernel behind
     its staging pass, matrix-core kernel reading buffer and carry in place (one launch;
     shapes it does not take -- M % 4 != 0, TONES -- fall back to the staged one)."""
     monkeypatch.setenv("GSDR_DDC_MFMA", "0" if request.param == "flat" else "1")
-    monkeypatch.setenv("GSDR_MFMA_ASM", {"mfma1": "3", "mfma16": "4", "mfma16w8": "5"}.get(request.param, "2"))
+    monkeypatch.setenv("GSDR_MFMA_ASM", {"mfma1": "3", "mfma16": "4", "mfma16w8": "5", "mfma16p": "4"}.get(request.param, "2"))
+    monkeypatch.setenv("GSDR_MFMA_PREC", "1" if request.param == "mfma16p" else "0")
     monkeypatch.setenv("GSDR_MFMA_RT", "2" if request.param == "mfma_rt2" else "0")
     return request.param
 
 
-@pytest.fixture(params=["staged", "direct", "x16", "x16w8"])
+@pytest.fixture(params=["staged", "direct", "x16", "x16w8", "x16p"])
 def mfma_engine(request, monkeypatch):
     """Matrix-core DDC behind its staging pass / reading buffer and carry in place / the ring
     loop on the 16x16x32 MFMA shape."""
     monkeypatch.setenv("GSDR_DDC_MFMA", "1")
-    monkeypatch.setenv("GSDR_MFMA_ASM", {"direct": "3", "x16": "4", "x16w8": "5"}.get(request.param, "2"))
+    monkeypatch.setenv("GSDR_MFMA_ASM", {"direct": "3", "x16": "4", "x16w8": "5", "x16p": "4"}.get(request.param, "2"))
+    monkeypatch.setenv("GSDR_MFMA_PREC", "1" if request.param == "x16p" else "0")
     return request.param
 
 
@@ -144,7 +146,7 @@ DIRECT_CASES = [
 
 @pytest.mark.parametrize("case", DIRECT_CASES, ids=lambda c: "N%d_M%d_F%d_L%d" % (c[0], c[2], c[3], c[4]))
 @pytest.mark.parametrize("impl", ["flat", "flat12", "flat16", "flat20", "simple16", "simple32",
-                                  "mfma", "mfma_rt2", "mfma16", "mfma16_rt2", "mfma16w8", "mfma_direct", "mfma_solo", "mfma_c", "mfma_t2",
+                                  "mfma", "mfma_rt2", "mfma16", "mfma16_rt2", "mfma16w8", "mfma16p", "mfma_direct", "mfma_solo", "mfma_c", "mfma_t2",
                                   "mfma_w2", "mfma_pk16"])
 def test_direct_parity(cuda_device, gsdr_lib, oracle_mod, monkeypatch, case, impl):
     """flat* = ddc_flat_kernel (packed FP32; sub-block length auto / forced),
@@ -157,6 +159,8 @@ def test_direct_parity(cuda_device, gsdr_lib, oracle_mod, monkeypatch, case, imp
     16 x 16 per wave, 48 MFMAs per block; _rt2: two row tiles per workgroup),
     mfma16w8 = ddc_mfma_ring16w8_kernel (that loop for workgroups of eight waves: 32 rows x 256 tones, the
     waves of a SIMD barrier-coupled partners, conversion shared by eight waves),
+    mfma16p = ddc_convert_kernel + ddc_mfma_ring16p_kernel (the operand converted once per buffer, the loop
+    copies 8-KiB images into its ring by LDS-DMA: the path of launches of many rounds, forced here),
     mfma_direct = ddc_mfma_ringd_kernel (the same loop reading buffer and carry in place: one
     launch per buffer, one scale per workgroup; M % 4 == 0, other shapes run the staged kernel),
     mfma_solo = ddc_mfma_asm_kernel (assembly main loop, every wave converts its own operand),
@@ -172,6 +176,7 @@ def test_direct_parity(cuda_device, gsdr_lib, oracle_mod, monkeypatch, case, imp
             monkeypatch.setenv("GSDR_MFMA_RT", "2")
         if impl.startswith("mfma16"):
             monkeypatch.setenv("GSDR_MFMA_ASM", "5" if impl == "mfma16w8" else "4")
+            monkeypatch.setenv("GSDR_MFMA_PREC", "1" if impl == "mfma16p" else "0")
             if impl == "mfma16_rt2":
                 monkeypatch.setenv("GSDR_MFMA_RT", "2")
         if impl == "mfma_direct":

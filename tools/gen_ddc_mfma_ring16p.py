@@ -1,28 +1,16 @@
 #!/usr/bin/env python3
-"""Generates gpu_sdr_amd/csrc/ddc_mfma_ring16_gen.h: main loop of ddc_mfma_ring16_kernel
-(gfx950) -- the LDS-ring loop of tools/gen_ddc_mfma_ring.py re-tiled for
-v_mfma_f32_16x16x32_f16.
+"""Generates gpu_sdr_amd/csrc/ddc_mfma_ring16p_gen.h: main loop of ddc_mfma_ring16p_kernel
+(gfx950) -- the 16x16x32 ring loop of tools/gen_ddc_mfma_ring16.py fed with PRE-CONVERTED operands.
 
-Why: every DDC workload runs at the package power cap, and under the
-cap the 16x16x32 shape delivers 12-15 % more FLOP/s than 32x32x16 at equal cycles per FLOP
-(MI355X_MICROARCH.md, DVFS give-back item 7).  Same arithmetic, same ring, same writers:
+For launches of many rounds (thousands of tones) every workgroup of a row tile repeats the same
+work on the same input: 3 scattered loads (64 cache lines each) and 28 conversion instructions per
+wave and block, to produce the tone-independent A operand -- the timing-only ablations price the
+loads at 11 % and the conversion at 3 % of such a launch.  Here a small pass (ddc_convert_kernel)
+converts every (row tile, block) ONCE per buffer into the 8-KiB slot image the ring holds, and the
+loop only copies images into its ring: two global_load_lds_dwordx4 per wave and block (1 KiB
+contiguous each, no VGPR, no VALU), three blocks ahead of their use in a ring of four slots.
 
-  * one wave = 32 rows x 32 tones = 2 x 2 tiles of 16 x 16, x (re, im): 8 accumulators of 4
-    registers (the 32 result registers of the 32x32 form, regrouped);
-  * a block of 32 samples = 2 k-steps of 16 samples (K = 32 reals): 48 MFMAs of 16 cycles
-    instead of 24 of 32.  A fragment (k-step k2, row half rh, hi|lo) is read from the ring
-    UNCHANGED in layout -- the writers still convert 8-sample k-steps -- with a per-lane base:
-    lane l takes old k-step 2*k2 + (l >> 5), old lane (16*rh + (l & 15)) + 32*((l >> 4) & 1);
-    conflict-free for ds_read_b128 (the 16 lanes of a service group differ in l & 15 only);
-  * MFMA order inside a k-step: (row half, hi|lo) major, so that an operand buffer is dead 8
-    or 4 MFMAs after its first use and is re-read one block later at least 24 MFMAs (384
-    cycles, the distance rule R1 was measured at) after its last use;
-  * the block phasor P exists per tone half: two dwordx2 loads per block instead of two dword
-    loads, 64 v_fma_f32 as before.
-
-Rules R1..R4 of tools/gen_ddc_mfma.py apply unchanged.
-
-    python3 tools/gen_ddc_mfma_ring16.py > gpu_sdr_amd/csrc/ddc_mfma_ring16_gen.h
+    python3 tools/gen_ddc_mfma_ring16p.py > gpu_sdr_amd/csrc/ddc_mfma_ring16p_gen.h
 """
 import os
 import sys
@@ -41,6 +29,7 @@ ABLATE = set(filter(None, os.environ.get("GEN_ABLATE", "").split(",")))
 PRIO = os.environ.get("GEN_PRIO", "none")
 KS = 4                     # k-steps per block (PK = 32)
 SLOT = KS * 2 * 1024       # bytes of one ring slot
+NSLOT = 4                  # ring slots: images arrive three blocks ahead
 
 # ---- register map (TT = 1) -------------------------------------------------
 VB = 12                    # v0..v11 stay with the compiler
@@ -68,6 +57,9 @@ NAGPR = 64
 SB = {"A": dict(x=36, t=38, p=40), "B": dict(x=60, t=62, p=64), "C": dict(x=76, t=78, p=0)}   # C: prologue only
 S_NLEFT, S_K, S_NHI1 = 42, 43, 44
 S_RD, S_RDN, S_WR = 45, 46, 47
+S_RD2 = 72     # slot of block b+2 (between RDN and WR)
+S_M0 = 73      # M0 on entry
+S_WRS = 74     # wave-uniform LDS base of this wave's two image pieces
 S_SC = 48      # s[48:49] = (S, S)
 S_T0, S_T1 = 50, 51
 S_PH = 59      # wave slot parity (HW_ID wave_id & 1): GEN_PRIO=hw
@@ -311,48 +303,51 @@ def frag_for(label, k2, rh, sp):
     return frag(k2, rh, sp)
 
 
+def image_pointer(par):
+    """SALU: s[SB[par].x] = image base + 8192 * min(S_K, nhi-1), then S_K += 1 (parity set `par`:
+    a scalar base is never rewritten under a queued load that reads it, rule R2)."""
+    S_X = SB[par]["x"]
+    return [
+        f"s_min_u32 s{S_T0}, s{S_K}, s{S_NHI1}",
+        f"s_lshl_b32 s{S_T1}, s{S_T0}, 13",
+        f"s_add_u32 s{S_X}, s{S_XB}, s{S_T1}",
+        f"s_addc_u32 s{S_X + 1}, s{S_XB + 1}, 0",
+        f"s_add_u32 s{S_K}, s{S_K}, 1",
+    ]
+
+
+def dma_ops(par, slot_sreg, which):
+    """One LDS-DMA piece of the image s[SB[par].x] into ring slot `slot_sreg`: which = 0 the hi
+    image of this wave's k-step (1 KiB), 1 the lo image.  M0 carries the wave-uniform LDS address;
+    it is written right in front of its only reader and not again for many MFMAs."""
+    S_X = SB[par]["x"]
+    return [
+        f"s_add_u32 m0, s{slot_sreg}, s{S_WRS}" if which == 0 else f"s_add_u32 m0, m0, 1024",
+        "s_nop 0",
+        f"global_load_lds_dwordx4 {'%[io_hi]' if which == 0 else '%[io_lo]'}, s[{S_X}:{S_X + 1}]",
+    ]
+
+
 def iteration(cnt, out, cur, prev, p_cur, p_prev, label):
-    """One block of 32 samples: 48 MFMAs.  cur/prev: C sets; p_cur/p_prev: P registers (4 each)."""
+    """One block of 32 samples: 48 MFMAs.  cur/prev: C sets; p_cur/p_prev: P registers (4 each).
+    Block b computes from ring slot RD, prefetches block b+1's first fragments from RDN and
+    starts the copy of block b+3's image into slot WR (free since the barrier that ended b-1)."""
     out.append(f"; ---- block iteration, C set {label}")
-    if PRIO == "ab":
-        out.append("s_setprio 1" if label == "A" else "s_setprio 0")
-    elif PRIO == "ba":
-        out.append("s_setprio 0" if label == "A" else "s_setprio 1")
-    elif PRIO == "hw":
-        # opposite phases for the two wave slots of a SIMD: slot parity p has priority in its
-        # blocks of parity p
-        want = 0 if label == "A" else 1
-        out.append(f"s_cmp_eq_u32 s{S_PH}, {want}")
-        out.append(f"s_cbranch_scc1 7{label}1f" if False else f"s_cbranch_scc1 {7 if label == 'A' else 8}f")
-        out.append("s_setprio 0")
-        out.append(f"s_branch {5 if label == 'A' else 6}f")
-        out.append(f"{7 if label == 'A' else 8}:")
-        out.append("s_setprio 1")
-        out.append(f"{5 if label == 'A' else 6}:")
-    elif PRIO == "hwstatic":
-        pass
     rot = rotate_ops(prev, p_prev)
-    prod = produce_ops()
     other = "B" if label == "A" else "A"
-    salu = advance_load_pointers(other)          # for the next iteration's loads
     S_P, N_P = SB[label]["p"], SB[other]["p"]
     NG = 48
     gaps = {g: [] for g in range(NG)}
-    V_RD, V_RDN, V_WR = ADDR[label]
-    N_RD, N_RDN, N_WR = ADDR[other]
+    V_RD, V_RDN, _ = ADDR[label]
+    N_RD, N_RDN, _ = ADDR[other]
 
     def read_frag(g, slot_reg, k2, rh, sp, into):
-        # ring slot layout (unchanged): old k-step ks at ks*2048, hi at +0, lo at +1024, old lane
-        # (row, hh) at 16*(row + 32*hh).  %[lane16] carries the per-lane part (see the kernel).
         off = k2 * 4096 + sp * 1024 + rh * 256
         gaps[g].append(("lds", f"ds_read_b128 {vr(into, 4)}, {vr(slot_reg)} offset:{off}", f"f{k2}{rh}{sp}"))
 
-    # this block's k-step 1 (ring slot RD); each buffer at least 24 MFMAs after its last use
     for (rh, sp, g) in ((0, 0, 8), (0, 1, 12), (1, 0, 20), (1, 1, 24)):
         assert g + NG - last_use(1, rh, sp) >= 24 and g < first_use(1, rh, sp) - 8
         read_frag(g, V_RD, 1, rh, sp, frag_for(label, 1, rh, sp))
-    # the next block's k-step 0 (ring slot RDN): row half 0 into its only buffer once that is
-    # free, row half 1 into the buffer the next iteration uses
     for (rh, sp, g) in ((0, 0, 32), (1, 0, 34), (0, 1, 36), (1, 1, 38)):
         if rh == 0:
             assert g - last_use(0, rh, sp) >= 24
@@ -362,46 +357,28 @@ def iteration(cnt, out, cur, prev, p_cur, p_prev, label):
     gaps[0].append(("vm", f"global_load_dwordx2 {vr(p_cur + 2, 2)}, %[po], s[{S_P}:{S_P + 1}] offset:128", "p" + label))
     gaps[1].append(("salu", f"s_add_u32 s{N_P}, s{S_P}, s{S_PSTRIDE}", None))
     gaps[1].append(("salu", f"s_addc_u32 s{N_P + 1}, s{S_P + 1}, 0", None))
-    for i, sx in enumerate(salu):
+    # image of block b+3 -> slot WR: pointer (this parity's set) in gaps 2..4, the two pieces at
+    # gaps 6 and 18 (M0 is rewritten 12 MFMAs after its first reader was issued)
+    for i, sx in enumerate(image_pointer(label)):
         gaps[2 + i // 2].append(("salu", sx, None))
-    # P*C of the previous block: two per gap in gaps 4..19, the rest behind the conversion
-    ri = 0
-    for g in range(4, 20):
-        for _ in range(2):
-            gaps[g].append(("rot", rot[ri], None))
-            ri += 1
-    # conversion of block b+2: gaps 20..33
-    pi = 0
-    for g in range(20, 34):
-        for _ in range(2):
-            if pi < len(prod):
-                gaps[g].append(("prod", prod[pi], None))
-                pi += 1
-    assert pi == len(prod), (pi, len(prod))
-    left = len(rot) - ri
-    for k in range(left):
-        g = 34 + (k * 14) // left
-        gaps[g].append(("rot", rot[ri], None))
-        ri += 1
-    assert ri == len(rot), ri
-    gaps[34].append(("ldsw", f"ds_write_b128 {vr(V_WR)}, {vr(HI4, 4)}", "wh"))
-    gaps[34].append(("ldsw", f"ds_write_b128 {vr(V_WR)}, {vr(LO4, 4)} offset:1024", "wl"))
-    # loads of block b+3 once the conversion has read XA/XB/HV
-    gaps[36].append(("gload", None, None))
-    # ring slot rotation and addresses of the next iteration (all ring accesses issued by gap 38)
-    if "noaddr" in ABLATE:         # timing-only (WRONG results): ring addresses never advance
-        pass
-    else:
-      gaps[40].append(("salu", f"s_mov_b32 s{S_T0}, s{S_RD}", None))
-      gaps[40].append(("salu", f"s_mov_b32 s{S_RD}, s{S_RDN}", None))
-      gaps[41].append(("salu", f"s_mov_b32 s{S_RDN}, s{S_WR}", None))
-      gaps[41].append(("salu", f"s_mov_b32 s{S_WR}, s{S_T0}", None))
-      gaps[43].append(("addr", f"v_add_u32 {vr(N_RD)}, s{S_RD}, %[lane16]", None))
-      gaps[44].append(("addr", f"v_add_u32 {vr(N_RDN)}, s{S_RDN}, %[lane16]", None))
-      gaps[45].append(("addr", f"v_add_u32 {vr(N_WR)}, s{S_WR}, %[wr16]", None))
+    for i, tx in enumerate(dma_ops(label, S_WR, 0)):
+        gaps[6].append(("dma" if tx.startswith("global") else "salu", tx, "dh" + label))
+    for i, tx in enumerate(dma_ops(label, S_WR, 1)):
+        gaps[18].append(("dma" if tx.startswith("global") else "salu", tx, "dl" + label))
+    # P*C of the previous block: 64 plain FMAs, gaps 4..47
+    for k, op in enumerate(rot):
+        gaps[4 + (k * 44) // len(rot)].append(("rot", op, None))
+    # ring slot rotation (four slots) and the read addresses of the next iteration, once every
+    # ring access of this iteration has been issued (gap 38)
+    gaps[40].append(("salu", f"s_mov_b32 s{S_T0}, s{S_RD}", None))
+    gaps[40].append(("salu", f"s_mov_b32 s{S_RD}, s{S_RDN}", None))
+    gaps[41].append(("salu", f"s_mov_b32 s{S_RDN}, s{S_RD2}", None))
+    gaps[41].append(("salu", f"s_mov_b32 s{S_RD2}, s{S_WR}", None))
+    gaps[42].append(("salu", f"s_mov_b32 s{S_WR}, s{S_T0}", None))
+    gaps[43].append(("addr", f"v_add_u32 {vr(N_RD)}, s{S_RD}, %[lane16]", None))
+    gaps[44].append(("addr", f"v_add_u32 {vr(N_RDN)}, s{S_RDN}, %[lane16]", None))
 
     first_rot = True
-    first_prod = True
     for g in range(NG):
         k2, m = divmod(g, 24)
         rh, sp_a, th, c, sp_b = ORDER[m]
@@ -414,31 +391,28 @@ def iteration(cnt, out, cur, prev, p_cur, p_prev, label):
             out.append(f"v_mfma_f32_16x16x32_f16 {vr(dst, 4)}, {vr(frag_for(label, k2, rh, sp_a), 4)}, "
                        f"{bfrag(k2, th, c, sp_b)}, {src_c}")
         for kind, text, tag in gaps[g]:
-            if kind == "lds" and "lds" in ABLATE:
-                pass
-            elif kind == "lds" or kind == "ldsw":
-                out.append(text)
-                cnt.issue_lgkm(tag)
+            if kind == "lds":
+                if "lds" not in ABLATE:
+                    out.append(text)
+                    cnt.issue_lgkm(tag)
             elif kind == "vm":
                 out.append(text)
                 cnt.issue_vm(tag)
+            elif kind == "dma":
+                if "gload" not in ABLATE:
+                    out.append(text)
+                    cnt.issue_vm(tag)
             elif kind == "rot":
                 if first_rot:
                     cnt.need_vm("pB" if label == "A" else "pA")
                     first_rot = False
                 if "rot" not in ABLATE:
                     out.append(text)
-            elif kind == "prod":
-                if first_prod:
-                    cnt.need_vm("xb")
-                    first_prod = False
-                if "prod" not in ABLATE:
-                    out.append(text)
-            elif kind == "gload":
-                if "gload" not in ABLATE:
-                    gload_ops(cnt, out, label)
             else:
                 out.append(text)
+    # the image this wave started one iteration ago (block b+2's) must have landed before the
+    # barrier publishes it: block b+1 prefetches from it
+    cnt.need_vm("dl" + other)
     cnt.drain_lgkm()
     if "bar" not in ABLATE:
         out.append("s_barrier")
@@ -449,16 +423,10 @@ def generate():
     cnt = Counters(out)
     o = out.append
     o("; ===== prologue =====")
-    o(f"s_mov_b32 s{S_XB}, %[xb_lo]")
-    o(f"s_mov_b32 s{S_XB + 1}, %[xb_hi]")
-    if DIRECT:
-        o(f"s_mov_b64 s[{S_EXEC}:{S_EXEC + 1}], exec")
-        o(f"s_mov_b32 s{S_CB}, %[cb_lo]")
-        o(f"s_mov_b32 s{S_CB + 1}, %[cb_hi]")
-        o(f"s_mov_b32 s{S_SMAX}, %[smax]")
-        o(f"s_mov_b32 s{S_CL8}, %[cl8]")
-    o(f"s_mov_b32 s{S_TB}, %[tp_lo]")
-    o(f"s_mov_b32 s{S_TB + 1}, %[tp_hi]")
+    o(f"s_mov_b32 s{S_M0}, m0")
+    o(f"s_mov_b32 s{S_XB}, %[ib_lo]")          # image base of this row tile, block 0
+    o(f"s_mov_b32 s{S_XB + 1}, %[ib_hi]")
+    o(f"s_mov_b32 s{S_WRS}, %[wrs]")
     o(f"s_mov_b32 s{SB['A']['p']}, %[pp_lo]")
     o(f"s_mov_b32 s{SB['A']['p'] + 1}, %[pp_hi]")
     o(f"s_mov_b32 s{S_BF}, %[bf_lo]")
@@ -467,138 +435,103 @@ def generate():
     o(f"s_mov_b32 s{S_NLEFT}, %[nhi]")
     o(f"s_add_u32 s{S_NHI1}, %[nhi], -1")
     o(f"s_mov_b32 s{S_K}, 0")
-    if PRIO in ("hw", "hwstatic"):
-        o(f"s_getreg_b32 s{S_PH}, hwreg(HW_REG_HW_ID, 0, 4)")
-        o(f"s_and_b32 s{S_PH}, s{S_PH}, 1")
-    if PRIO == "hwstatic":
-        # the wave in the odd slot of its SIMD (the later arrival) takes priority for good
-        o(f"s_cmp_eq_u32 s{S_PH}, 1")
-        o("s_cbranch_scc0 9f")
-        o("s_setprio 1")
-        o("9:")
-    o(f"v_mov_b32 {vr(V_SC)}, %[scale]")
     o(f"s_mov_b32 s{S_RD}, 0")
     o(f"s_mov_b32 s{S_RDN}, {SLOT}")
-    o(f"s_mov_b32 s{S_WR}, {2 * SLOT}")
+    o(f"s_mov_b32 s{S_RD2}, {2 * SLOT}")
+    o(f"s_mov_b32 s{S_WR}, {3 * SLOT}")
     o("s_nop 4")
-    # phasor-table operand images -> AGPRs (16 x 16 bytes per lane, 1 KiB apart).  Four
-    # bases, all computed before the first load: a base is never rewritten under a load.
     BF = [S_BF, 66, 68, 70]
     for j in range(1, 4):
         o(f"s_add_u32 s{BF[j]}, s{S_BF}, {4096 * j}")
         o(f"s_addc_u32 s{BF[j] + 1}, s{S_BF + 1}, 0")
     o("s_nop 4")
-    # (a workgroup that runs the loop for a second row tile keeps them: %[first] == 0)
-    if not DIRECT:
-        o("s_cmp_eq_u32 %[first], 0")
-        o("s_cbranch_scc1 4f")
+    o("s_cmp_eq_u32 %[first], 0")
+    o("s_cbranch_scc1 4f")
     for f in range(16):
         b = BF[f // 4]
         if "bimg" not in ABLATE:
             o(f"global_load_dwordx4 {ar(4 * f)}, %[bo], s[{b}:{b + 1}] offset:{(f % 4) * 1024}")
-    if not DIRECT:
-        o("4:")
-    # zero: C set B, accumulators, P_B
+    o("4:")
     for base in (CB[0], CB[1], ACC[0], ACC[1]):
         for i in range(16):
             o(f"v_mov_b32 {vr(base + i)}, 0")
     for i in range(4):
         o(f"v_mov_b32 {vr(PB + i)}, 0")
-    # blocks 0, 1 and 2 are loaded at once (one round trip): block 0 into the input
-    # registers, 1 and 2 into the still idle operand buffers; 0 and 1 are converted
-    # into ring slots 0 and 1, block 2 is moved to the input registers for trip 0
-    T1 = (F0, F0 + 4, F0 + 8)          # xa, xb, hv of block 1
-    T2 = (F0 + 12, F0 + 16, F0 + 20)   # of block 2
-    OFF_C = (CA[0], CA[0] + 1)          # offsets of block 2: set A is written by the first MFMA only
-    out.extend(advance_load_pointers("A"))
-    if DIRECT:
-        out.extend(offset_ops("A"))
-    out.extend(advance_load_pointers("B"))
-    if DIRECT:
-        out.extend(offset_ops("B"))
-    out.extend(advance_load_pointers("C"))
-    if DIRECT:
-        out.extend(offset_ops("C", OFF_C))
-    o("s_nop 4")
-    gload_ops(cnt, out, "A")
-    gload_ops(cnt, out, "B", *T1)
-    gload_ops(cnt, out, "C", *T2, off=OFF_C)
-    o("s_waitcnt vmcnt(0)")          # the phasor images as well
-    cnt.vm = []
-    for blk, src in ((0, (None, None, None)), (1, T1)):
-        out.extend(produce_ops(*src))
-        o(f"v_add_u32 {vr(ADDR['B'][blk])}, {blk * SLOT}, %[wr16]")
-        o(f"ds_write_b128 {vr(ADDR['B'][blk])}, {vr(HI4, 4)}")
-        o(f"ds_write_b128 {vr(ADDR['B'][blk])}, {vr(LO4, 4)} offset:1024")
-        o("s_waitcnt lgkmcnt(0)")
-    for i in range(4):
-        o(f"v_mov_b32 {vr(XA + i)}, {vr(T2[0] + i)}")
-        o(f"v_mov_b32 {vr(XB + i)}, {vr(T2[1] + i)}")
-        o(f"v_mov_b32 {vr(HV + i)}, {vr(T2[2] + i)}")
-    out.extend(advance_load_pointers("A"))   # block 3: iteration 0 ("A") loads it
-    if DIRECT:
-        out.extend(offset_ops("A"))
-    V_RD, V_RDN, V_WR = ADDR["A"]
+    # images of blocks 0, 1, 2 into slots 0, 1, 2 (pointer sets A, B, C: one per load pair)
+    for par, slot in (("A", S_RD), ("B", S_RDN), ("C", S_RD2)):
+        out.extend(image_pointer(par))
+        o("s_nop 4")
+        out.extend(dma_ops(par, slot, 0))
+        o("s_nop 4")
+        out.extend(dma_ops(par, slot, 1))
+        o("s_nop 4")
+    V_RD, V_RDN, _ = ADDR["A"]
     o(f"v_add_u32 {vr(V_RD)}, s{S_RD}, %[lane16]")
     o(f"v_add_u32 {vr(V_RDN)}, s{S_RDN}, %[lane16]")
-    o(f"v_add_u32 {vr(V_WR)}, s{S_WR}, %[wr16]")
-    o("s_waitcnt lgkmcnt(0)")
+    o("s_waitcnt vmcnt(0)")          # the phasor images and the three slot images
     o("s_barrier")
     for rh in range(2):
         for sp in range(2):
             o(f"ds_read_b128 {vr(frag_for('A', 0, rh, sp), 4)}, {vr(V_RD)} offset:{sp * 1024 + rh * 256}")
     o("s_waitcnt lgkmcnt(0)")
     cnt.lgkm = []
-    # steady state entry: vm = [hv, xa, xb]; the loop expects [p_prev, hv, xa, xb]
-    XL = ["hv", "xa", "xb", "xa", "xb"] if DIRECT else ["hv", "xa", "xb"]
-    cnt.vm = ["prB", "pB"] + XL
-    o("; ===== main loop, two blocks per trip =====")
+
+    def trip(out_, cnt_):
+        iteration(cnt_, out_, CA, CB, PA, PB, "A")
+        out_.append(f"s_sub_u32 s{S_NLEFT}, s{S_NLEFT}, 1")
+        out_.append(f"s_cmp_eq_u32 s{S_NLEFT}, 0")
+        out_.append("s_cbranch_scc1 2f")
+        iteration(cnt_, out_, CB, CA, PB, PA, "B")
+        out_.append(f"s_sub_u32 s{S_NLEFT}, s{S_NLEFT}, 1")
+        out_.append(f"s_cmp_lg_u32 s{S_NLEFT}, 0")
+        out_.append("s_cbranch_scc1 1b")
+
+    state = []
+    for _ in range(4):
+        probe = Counters([])
+        probe.vm = list(state)
+        trip(probe.out, probe)
+        assert probe.lgkm == []
+        if probe.vm == state:
+            break
+        state = list(probe.vm)
+    else:
+        raise AssertionError("no steady state")
+    cnt.vm = list(state)
+    o(f"; ===== main loop, two blocks per trip; vm at the top: {state}")
     o("1:")
-    iteration(cnt, out, CA, CB, PA, PB, "A")
-    o(f"s_sub_u32 s{S_NLEFT}, s{S_NLEFT}, 1")
-    o(f"s_cmp_eq_u32 s{S_NLEFT}, 0")
-    o("s_cbranch_scc1 2f")
-    state_a = (list(cnt.lgkm), list(cnt.vm))
-    iteration(cnt, out, CB, CA, PB, PA, "B")
-    o(f"s_sub_u32 s{S_NLEFT}, s{S_NLEFT}, 1")
-    o(f"s_cmp_lg_u32 s{S_NLEFT}, 0")
-    o("s_cbranch_scc1 1b")
-    if "gload" not in ABLATE:
-        assert cnt.lgkm == [] and cnt.vm == ["prB", "pB"] + XL, (cnt.lgkm, cnt.vm)
-        assert state_a == ([], ["prA", "pA"] + XL), state_a
-    # exits: P*C of the last block
-    o("; last block was in set B")
+    trip(out, cnt)
+    assert cnt.lgkm == [] and cnt.vm == state, (cnt.lgkm, cnt.vm, state)
     o("s_waitcnt vmcnt(0)")
     o("s_nop 15")
     o("s_nop 15")
     out.extend(rotate_ops(CB, PB))
     o("s_branch 3f")
     o("2:")
-    o("; last block was in set A")
-
-
     o("s_waitcnt vmcnt(0)")
     o("s_nop 15")
     o("s_nop 15")
     out.extend(rotate_ops(CA, PA))
     o("3:")
-    # hand the accumulators to the C++ epilogue through LDS (the ring is idle: every
-    # wave passed the barrier that ended the last iteration)
+    # every image copy has landed (vmcnt(0) above) and every wave is past the last barrier: the
+    # ring is idle, the accumulators go to the C++ epilogue through it
+    o("s_barrier")
     for q in range(8):
         base = (ACC[0] if q < 4 else ACC[1]) + 4 * (q & 3)
         o(f"ds_write_b128 %[accaddr], {vr(base, 4)} offset:{q * 1024}")
     o("s_waitcnt lgkmcnt(0)")
+    o(f"s_mov_b32 m0, s{S_M0}")
     return out
 
 
 def main():
     lines = generate()
-    PFX = "GSDR_MFMA_RING16"
-    print("// GENERATED by tools/gen_ddc_mfma_ring16.py -- do not edit.")
-    print("// Main loop of ddc_mfma_ring16_kernel (v_mfma_f32_16x16x32_f16): see the generator for the schedule and register map.")
+    PFX = "GSDR_MFMA_RING16P"
+    print("// GENERATED by tools/gen_ddc_mfma_ring16p.py -- do not edit.")
+    print("// Main loop of ddc_mfma_ring16p_kernel (pre-converted operands by LDS-DMA, v_mfma_f32_16x16x32_f16): see the generator for the schedule and register map.")
     print("#pragma once")
     print(f"#define {PFX}_VB {VB}")
-    print(f"#define {PFX}_BYTES {3 * SLOT}")
+    print(f"#define {PFX}_BYTES {NSLOT * SLOT}")
     print(f"#define {PFX}_TEXT \\")
     for ln in lines:
         if ln.startswith(";"):
