@@ -305,6 +305,7 @@ def host_api_rates(wl, device, seed, seconds=0.4):
     outs = [torch.empty(dem.out_capacity, dtype=torch.complex64).pin_memory() for _ in range(PIPE_DEPTH)]
     xn, on = [t.numpy() for t in xin], [t.numpy() for t in outs]
     res = {}
+    dem.prepare()          # what the C++ class does in its constructor (like the reference's): no lazy allocation in the loop
     for _ in range(3):
         dem.process(xn[0], on[0])
     t0, n = time.perf_counter(), 0

@@ -469,7 +469,7 @@ int setup_mfma(gsdr_demod *h, bool direct, const std::vector<long long> &tone) {
     // GSDR_MFMA_PREC: 1 = always (tests), 0 = never, default = per launch in enqueue_mfma:
     //   in-order entries      launches of four rounds of workgroups or more (-9 % at 16 k ... 64 k tones;
     //                         below that the pass, which runs in front of the loop there, costs more);
-    //   overlapped entries    launches of a full round or more with windows of 32 blocks or more: the
+    //   overlapped entries    launches of half a round or more with windows of 32 blocks or more: the
     //                         pass of buffer j+1 runs beside the loop of buffer j (C3 139 -> 130.5 us per
     //                         buffer, TONES 1024/1230 76.8 -> 74.0; C2, 13 blocks: neutral, not used).
     if (h->mf_kind == gsdr::MfmaKernel::AsmRing16) {
@@ -479,7 +479,7 @@ int setup_mfma(gsdr_demod *h, bool direct, const std::vector<long long> &tone) {
         const long long nhi = (pl.nk8 + 3) / 4;
         const long long wgs4 = ((ngt_max + 7) / 8) * 8 * sh.ntq;
         bool want = h->prec_mode == 1 ||
-                    (h->prec_mode < 0 && (wgs4 >= 4LL * (h->simds / 2) || (wgs4 >= h->simds / 2 && nhi >= 32)));
+                    (h->prec_mode < 0 && (wgs4 >= 4LL * (h->simds / 2) || (wgs4 >= h->simds / 4 && nhi >= 32)));
         const size_t img_n = (size_t)ngt_max * (size_t)nhi * 512;   // uint4 per image set
         if (want && img_n * sizeof(uint4) > (size_t)8 << 30) want = false;
         for (int i = 0; i < kStageSets && want; ++i) HIPCHK(h, dev_alloc(&h->d_img[i], img_n));
@@ -697,7 +697,7 @@ int enqueue_mfma(gsdr_demod *h, const float2 *in, float2 *raw, long long raw_new
         const long long wgs4 = (long long)((a.sh.ngt + 7) / 8) * 8 * a.sh.ntq;
         const int nhi = (a.sh.nk8 + 3) / 4;
         use_prec = h->prec_mode == 1 || wgs4 >= 4LL * (h->simds / 2) ||
-                   (h->pipe_overlap && wgs4 >= h->simds / 2 && nhi >= 32);
+                   (h->pipe_overlap && wgs4 >= h->simds / 4 && nhi >= 32);
     }
     if (use_prec) {
         kind = gsdr::MfmaKernel::AsmRing16P;
