@@ -56,30 +56,48 @@ def pmc(src_dir, dst):
     return out
 
 
+def dominant(stats):
+    """the gsdr:: DDC / chirp kernel with the largest share of the in-order run"""
+    best = None
+    for k, v in (stats or {}).items():
+        if ("ddc_mfma" in k or "chirp" in k or "ddc_flat" in k) and "convert" not in k:
+            if best is None or v[1] > best[1]:
+                best = (k, v[1])
+    return best[0] if best else None
+
+
+def kernel_stats2(src_dir, dst):
+    """like kernel_stats, but returns {kernel: (avg_us, total_ns)}"""
+    f = newest(os.path.join(src_dir, "trace", "**", "*kernel_stats.csv"))
+    if not f:
+        return None
+    rows = list(csv.reader(open(f)))
+    keep = [rows[0]] + [r for r in rows[1:] if r and r[0].startswith("gsdr::")]
+    with open(dst, "w", newline="") as o:
+        csv.writer(o, quoting=csv.QUOTE_ALL).writerows(keep)
+    return {r[0].split("(")[0]: (float(r[3]) / 1e3, float(r[2])) for r in keep[1:]}
+
+
 traffic = {}
-for wl, dom in (("c2", "ddc_mfma_ring16_kernel"), ("c3", "ddc_mfma_ring16_kernel"), ("pfb", "ddc_mfma_ring16_kernel"),
-                ("c4", "chirp_lockin_kernel")):
+for wl in ("c2", "c3", "pfb", "c4"):
     src = os.path.join(ROOT, "gpurun_out", "prof_" + wl)
     if not os.path.isdir(src):
         continue
-    st = kernel_stats(src, os.path.join(OUT, f"{TAG}_{wl}_kernel_stats.csv"))
+    st = kernel_stats2(src, os.path.join(OUT, f"{TAG}_{wl}_kernel_stats.csv"))
     pm = pmc(src, os.path.join(OUT, f"{TAG}_{wl}_pmc.json"))
-    ov = overlap(src)
     io = os.path.join(ROOT, "gpurun_out", "prof_" + wl + "_io")
-    st_io = kernel_stats(io, os.path.join(OUT, f"{TAG}_{wl}_inorder_kernel_stats.csv")) if os.path.isdir(io) else None
-    k = "gsdr::" + dom
+    st_io = kernel_stats2(io, os.path.join(OUT, f"{TAG}_{wl}_inorder_kernel_stats.csv")) if os.path.isdir(io) else None
+    k = dominant(st_io) or dominant(st)
     c = pm.get(k, {})
-    entry = {"kernel": k, "rocprof_avg_us": round(st[k], 2) if st and k in st else None}
-    if st_io and k in st_io:
-        entry["rocprof_avg_us_inorder"] = round(st_io[k], 2)
-    if ov:
-        entry["timeline"] = ov
+    entry = {"kernel_inorder": k, "rocprof_avg_us_inorder": round(st_io[k][0], 2) if st_io and k in st_io else None,
+             "overlapped_entry_kernels_avg_us": {kk: round(v[0], 2) for kk, v in (st or {}).items()
+                                                 if "ddc" in kk or "chirp" in kk or "absmax" in kk}}
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         entry.update(FETCH_SIZE_KB_raw=c["FETCH_SIZE"], WRITE_SIZE_KB_raw=c["WRITE_SIZE"],
                      hbm_bytes_per_launch=int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024),
-                     note="FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of streamed reads); "
-                          "counters are collected with the dispatches serialised (kernel alone on the chip); "
-                          "scalar-load and 8-B-per-lane store widths are uncalibrated, so treat as +-2x")
+                     note="counters of the in-order kernel (dispatches serialised: kernel alone on the chip); FETCH_SIZE doubled per "
+                          "MI355X_MICROARCH.md (gfx950 reports 1/2 of streamed reads); scalar-load and 8-B-per-lane store widths are "
+                          "uncalibrated, so treat as +-2x")
     traffic[wl] = entry
-    print(wl, json.dumps(entry))
+    print(wl, json.dumps(entry)[:400])
 json.dump(traffic, open(os.path.join(OUT, "traffic.json"), "w"), indent=1)

@@ -187,6 +187,7 @@ def test_no_cpu_fallback_in_product():
                                         ("gen_ddc_mfma_ring.py --direct", "ddc_mfma_ringd_gen.h"),
                                         ("gen_ddc_mfma_ring16.py", "ddc_mfma_ring16_gen.h"),
                                         ("gen_ddc_mfma_ring16w8.py", "ddc_mfma_ring16w8_gen.h"),
+                                        ("gen_ddc_mfma_ring16p.py", "ddc_mfma_ring16p_gen.h"),
                                         ("gen_ddc_mfma.py", "ddc_mfma_gen.h"),
                                         ("gen_ddc_steps.py", "ddc_steps_gen.h")])
 def test_generated_headers_are_current(gen, header):
@@ -204,3 +205,38 @@ def test_generated_headers_are_current(gen, header):
     if produced != committed:
         open(path, "w").write(committed)      # leave the tree as it was
     assert produced == committed
+
+
+RING_HEADERS = ["ddc_mfma_ring_gen.h", "ddc_mfma_ringd_gen.h", "ddc_mfma_ring16_gen.h", "ddc_mfma_ring16w8_gen.h",
+                "ddc_mfma_ring16p_gen.h"]
+
+
+def test_generated_loops_obey_the_hazard_rules(tmp_path):
+    """tools/check_asm_rules.py re-derives rules R1-R3 of DESIGN.md section 4.1 (operand registers
+    not rewritten under an MFMA, address registers not rewritten under a queued memory
+    instruction, no packed FP32) from the emitted instruction stream of every ring loop -- and
+    notices when one is broken (three seeded violations)."""
+    import importlib.util
+    import re
+    spec = importlib.util.spec_from_file_location("check_asm_rules", os.path.join(ROOT, "tools", "check_asm_rules.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    for h in RING_HEADERS:
+        assert chk.check(os.path.join(ROOT, "gpu_sdr_amd", "csrc", h)) == [], h
+    src = open(os.path.join(ROOT, "gpu_sdr_amd", "csrc", "ddc_mfma_ring16_gen.h")).read()
+    lines = src.split("\n")
+    loop_at = next(i for i, ln in enumerate(lines) if ln.strip().startswith('"1:'))
+    mf = next(i for i in range(loop_at, len(lines)) if "v_mfma" in lines[i])
+    a_op = re.search(r"v_mfma\S+ v\[\d+:\d+\], (v\[\d+:\d+\])", lines[mf]).group(1)
+    rd = next(i for i in range(loop_at, len(lines)) if "ds_read_b128" in lines[i])
+    addr = re.search(r"ds_read_b128 v\[\d+:\d+\], (v\d+)", lines[rd]).group(1)
+    seeded = {
+        "R1": (mf + 1, f'    "ds_read_b128 {a_op}, {addr}\\n\\t" \\'),
+        "R2": (rd + 1, f'    "v_add_u32 {addr}, s45, v0\\n\\t" \\'),
+        "R3": (mf + 1, '    "v_pk_mul_f32 v[20:21], v[20:21], v[22:23]\\n\\t" \\'),
+    }
+    for rule, (at, text) in seeded.items():
+        bad = tmp_path / f"bad_{rule}.h"
+        bad.write_text("\n".join(lines[:at] + [text] + lines[at:]))
+        errs = chk.check(str(bad))
+        assert any(f" {rule}:" in e for e in errs), (rule, errs[:3])
