@@ -94,7 +94,16 @@ def init_group(backend: str):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
     if not dist.is_initialized():
-        dist.init_process_group(backend=backend)
+        # gloo announces its connections on stdout; stdout carries ONE line, the result: park fd 1 on fd 2 meanwhile
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend=backend)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     return dist
 
 
@@ -549,6 +558,10 @@ def measure(engine, key, device, seed, steps, warmup, dist, api, min_seconds, wi
                     launches_in_flight=round(kt / (r["local_elapsed"] / r["total_steps"]), 2),
                     note="average launch duration inside the timed region of `value`, where up to "
                          f"{PIPE_DEPTH} launches share the chip")
+    if roof and ri is not r and ri["kernel"] != r["kernel"]:
+        roof["note"] = (f"kernel / kernel_us are those of the in-order pass ({ri['kernel']}: the library picks the kernel per "
+                        f"launch, DESIGN.md 4.1a/4.1b); the overlapped entry that `value` is timed through ran {r['kernel']} "
+                        f"(+ ddc_convert_kernel when that is the pre-converted path); same tables, bit-identical results")
     res["roofline"], res["roofline_hbm"] = roof, roof_hbm
     return res
 
