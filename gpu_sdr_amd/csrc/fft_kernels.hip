@@ -25,26 +25,40 @@
 
 namespace gsdr {
 
+// No packed FP32 in these kernels: a NOISE handle may run beside the matrix-core DDC of another handle
+// (two front-ends on one GPU), and v_pk_*_f32 with a high-half broadcast is unreliable in a wave that
+// shares its SIMD with an MFMA loop (rule R3, DESIGN.md section 4.1, tools/ubench_pk_hazard.hip).
+#define GSDR_NO_PK __attribute__((target("no-packed-fp32-ops")))
+
 namespace {
 
+// (make_float2 of the HIP headers is not always_inline: inside a kernel with other target features it
+//  would stay a real call, s_swappc_b64 -- `make asm` + grep is the check)
+__device__ __forceinline__ float2 mk2(float x, float y) {
+    float2 v;
+    v.x = x;
+    v.y = y;
+    return v;
+}
+
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+    return mk2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
 template <int R>
 __device__ __forceinline__ void butterfly(float2 (&u)[R], const float2 *__restrict__ tw, int n) {
     if constexpr (R == 2) {
         const float2 a = u[0], b = u[1];
-        u[0] = make_float2(a.x + b.x, a.y + b.y);
-        u[1] = make_float2(a.x - b.x, a.y - b.y);
+        u[0] = mk2(a.x + b.x, a.y + b.y);
+        u[1] = mk2(a.x - b.x, a.y - b.y);
     } else if constexpr (R == 4) {
         // forward DFT-4: w = -i
-        const float2 a0 = make_float2(u[0].x + u[2].x, u[0].y + u[2].y), a1 = make_float2(u[0].x - u[2].x, u[0].y - u[2].y);
-        const float2 b0 = make_float2(u[1].x + u[3].x, u[1].y + u[3].y), b1 = make_float2(u[1].x - u[3].x, u[1].y - u[3].y);
-        u[0] = make_float2(a0.x + b0.x, a0.y + b0.y);
-        u[2] = make_float2(a0.x - b0.x, a0.y - b0.y);
-        u[1] = make_float2(a1.x + b1.y, a1.y - b1.x);   // a1 - i*b1
-        u[3] = make_float2(a1.x - b1.y, a1.y + b1.x);   // a1 + i*b1
+        const float2 a0 = mk2(u[0].x + u[2].x, u[0].y + u[2].y), a1 = mk2(u[0].x - u[2].x, u[0].y - u[2].y);
+        const float2 b0 = mk2(u[1].x + u[3].x, u[1].y + u[3].y), b1 = mk2(u[1].x - u[3].x, u[1].y - u[3].y);
+        u[0] = mk2(a0.x + b0.x, a0.y + b0.y);
+        u[2] = mk2(a0.x - b0.x, a0.y - b0.y);
+        u[1] = mk2(a1.x + b1.y, a1.y - b1.x);   // a1 - i*b1
+        u[3] = mk2(a1.x - b1.y, a1.y + b1.x);   // a1 + i*b1
     } else {
         // odd prime: out[q] = sum_r u[r] * w_R^(q r), roots from the table (n is a multiple of R)
         float2 root[R];
@@ -70,7 +84,7 @@ __device__ __forceinline__ void butterfly(float2 (&u)[R], const float2 *__restri
 
 // one Stockham stage of radix R over `batch` transforms of length n; p = product of earlier radices
 template <int R>
-__global__ __launch_bounds__(256) void fft_pass_kernel(const float2 *__restrict__ x, float2 *__restrict__ y, int n, int p,
+__global__ __launch_bounds__(256) GSDR_NO_PK void fft_pass_kernel(const float2 *__restrict__ x, float2 *__restrict__ y, int n, int p,
                                                        const float2 *__restrict__ tw, long long total) {
     const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
     if (g >= total) return;
@@ -96,12 +110,12 @@ __global__ __launch_bounds__(256) void fft_pass_kernel(const float2 *__restrict_
 
 // ref: polyphase_filter, cpp/kernels.cu:474-516 -- frames[r][k] = sum_i raw[(r+i)*n + k] * w[i*n + k],
 // float accumulate in loop order, for the r < frames_n frames that are complete
-__global__ __launch_bounds__(256) void pfb_filter_kernel(const float2 *__restrict__ raw, const float *__restrict__ w, int n,
+__global__ __launch_bounds__(256) GSDR_NO_PK void pfb_filter_kernel(const float2 *__restrict__ raw, const float *__restrict__ w, int n,
                                                          int avg, long long total, float2 *__restrict__ frames) {
     const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
     if (g >= total) return;
     const int k = (int)(g % n);
-    float2 acc = make_float2(0.f, 0.f);
+    float2 acc = mk2(0.f, 0.f);
     for (int i = 0; i < avg; ++i) {
         const float2 s = raw[g + (size_t)i * n];
         const float wi = w[(size_t)i * n + k];
@@ -112,30 +126,30 @@ __global__ __launch_bounds__(256) void pfb_filter_kernel(const float2 *__restric
 }
 
 // Bluestein, step 1: a[b][j] = x[b][j] * conj(chirp[j]) for j < n, zero up to m
-__global__ __launch_bounds__(256) void bluestein_pre_kernel(const float2 *__restrict__ x, const float2 *__restrict__ chirp, int n,
+__global__ __launch_bounds__(256) GSDR_NO_PK void bluestein_pre_kernel(const float2 *__restrict__ x, const float2 *__restrict__ chirp, int n,
                                                             int m, long long total, float2 *__restrict__ a) {
     const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
     if (g >= total) return;
     const long long b = g / m;
     const int j = (int)(g - b * m);
-    float2 v = make_float2(0.f, 0.f);
+    float2 v = mk2(0.f, 0.f);
     if (j < n) {
         const float2 c = chirp[j];
-        v = cmul(x[(size_t)b * n + j], make_float2(c.x, -c.y));
+        v = cmul(x[(size_t)b * n + j], mk2(c.x, -c.y));
     }
     a[g] = v;
 }
 
 // step 2: d = conj(A * Bhat): the inverse transform is then a forward one (IFFT(z) = conj(FFT(conj z))/m)
-__global__ __launch_bounds__(256) void bluestein_mul_kernel(float2 *__restrict__ a, const float2 *__restrict__ bhat, int m, long long total) {
+__global__ __launch_bounds__(256) GSDR_NO_PK void bluestein_mul_kernel(float2 *__restrict__ a, const float2 *__restrict__ bhat, int m, long long total) {
     const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
     if (g >= total) return;
     const float2 v = cmul(a[g], bhat[g % m]);
-    a[g] = make_float2(v.x, -v.y);
+    a[g] = mk2(v.x, -v.y);
 }
 
 // step 3: X[b][k] = conj(chirp[k]) * conj(e[b][k]) / m, k < n
-__global__ __launch_bounds__(256) void bluestein_post_kernel(const float2 *__restrict__ e, const float2 *__restrict__ chirp, int n,
+__global__ __launch_bounds__(256) GSDR_NO_PK void bluestein_post_kernel(const float2 *__restrict__ e, const float2 *__restrict__ chirp, int n,
                                                              int m, long long total, float2 *__restrict__ out) {
     const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
     if (g >= total) return;
@@ -143,8 +157,8 @@ __global__ __launch_bounds__(256) void bluestein_post_kernel(const float2 *__res
     const int k = (int)(g - b * n);
     const float2 c = chirp[k], v = e[(size_t)b * m + k];
     const float inv = 1.f / (float)m;
-    const float2 r = cmul(make_float2(c.x, -c.y), make_float2(v.x, -v.y));
-    out[g] = make_float2(r.x * inv, r.y * inv);
+    const float2 r = cmul(mk2(c.x, -c.y), mk2(v.x, -v.y));
+    out[g] = mk2(r.x * inv, r.y * inv);
 }
 
 inline unsigned grid_for(long long total) { return (unsigned)((total + 255) / 256); }
