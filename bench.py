@@ -269,7 +269,8 @@ def time_workload(engine, wl, device, seed, steps, warmup, dist=None, n_tones=No
     if fixed_repeats:
         repeats = int(fixed_repeats)
     else:
-        repeats = max(1, int(math.ceil(min_seconds / max(est, 1e-9))))
+        # (the untimed pass runs warmer caches and a cooler chip than the steady state: aim 15 % over)
+        repeats = max(1, int(math.ceil(1.15 * min_seconds / max(est, 1e-9))))
         repeats = max(1, min(repeats, int(max_seconds / max(est, 1e-9)) or 1))
     total = steps * repeats
     every = PROFILE_EVERY if profile_every is None else profile_every
