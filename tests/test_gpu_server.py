@@ -94,9 +94,18 @@ def test_get_noise_direct_over_tcp(server):
         rows.append(z.reshape(-1, 16))                                    # Packets_to_file: (samples, channels)
     reply = recv_async(asyn)
     assert reply["type"] == "ack" and "EOM" in reply["payload"]
-    y = np.concatenate(rows)[8:]
-    # TX comb with ampl 1/16 per tone, looped back and demodulated: every channel sits at 1/16
-    assert np.abs(y - 1.0 / 16).max() < 2e-4
+    y = np.concatenate(rows)
+    # TX comb with ampl 1/16 per tone, looped back and demodulated: every channel sits at 1/16 ...
+    assert np.abs(y[8:] - 1.0 / 16).max() < 2e-4
+    # ... and, packet for packet, on what the oracle computes for the same chain: the reference's TX tone
+    # comb (tone_gen: kernels.cu:589-684) into the DIRECT demodulator (process_direct: USRP_demodulator.cpp:400-464)
+    import oracle
+    oracle.build()
+    rate, L = 100000000, 1000000
+    ref = oracle.Direct(tones, rate, 100, cmd["A_RX2"]["pf_average"], L)
+    want = np.concatenate([ref.process(oracle.tone_gen(tones, [1.0 / 16] * 16, rate, k * L, L)) for k in range(3)])
+    err = np.linalg.norm(y - want, axis=0) / np.linalg.norm(want, axis=0)
+    assert err.max() <= 1e-5, err.max()
     # a malformed command is nack'ed and the server keeps serving
     bad = dict(cmd)
     bad = {k: v for k, v in cmd.items() if k != "B_RX2"}
@@ -118,3 +127,14 @@ def test_single_vna_over_tcp(server):
         got.append(np.frombuffer(recv_all(data, int(h["length"]) * 8), dtype=np.complex64))
     assert "EOM" in recv_async(asyn)["payload"]
     np.testing.assert_allclose(np.concatenate(got), 0.5 + 0j, rtol=0, atol=3e-6)     # flat S21 of the loop-back
+    # the same chain through the oracle: TX chirp law (kernels.cu:335-372) into the chirp demodulator + lock-in
+    import oracle
+    oracle.build()
+    rate, L = 200000000, 1000000
+    rx = cmd["A_RX2"]
+    cp = oracle.chirp_params(rate, rx["freq"][0], rx["chirp_f"][0], rx["swipe_s"][0], rx["chirp_t"][0])
+    ref = oracle.Chirp(rate, rx["freq"][0], rx["chirp_f"][0], rx["swipe_s"][0], rx["chirp_t"][0], rx["decim"], L)
+    want = np.concatenate([ref.process(oracle.chirp_gen(cp, k * L, L, 0.5)) for k in range(2)])
+    got = np.concatenate(got)
+    assert got.shape == want.shape
+    assert np.linalg.norm(got - want) / np.linalg.norm(want) <= 1e-5
