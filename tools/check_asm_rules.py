@@ -14,9 +14,7 @@ across the back edge are seen) and fails loudly:
   R2  the address VGPRs, the scalar base pair and M0 of a queued LDS / global / LDS-DMA
       instruction are not rewritten before R2_MIN MFMAs have been issued behind it (measured: a
       rewrite 4 MFMAs later was seen by half of the lanes; the generators keep per-parity sets);
-  R3  no packed FP32 arithmetic (v_pk_*_f32) anywhere in the loop;
-  R4  the accumulators of the previous block (the C set the rotation reads) are not written by an
-      MFMA of the current block before the rotation has read them.
+  R3  no packed FP32 arithmetic (v_pk_*_f32) anywhere in the loop.
 
     python3 tools/check_asm_rules.py gpu_sdr_amd/csrc/ddc_mfma_ring16_gen.h [...]
 """
@@ -120,13 +118,12 @@ def check(path):
             # R1: LDS / global returns into a recent MFMA operand
             if op.startswith("ds_read") or (op.startswith("global_load") and "lds" not in op):
                 for w in written:
-                    if w in last_operand_use and mfma_cycles - last_operand_use[w] - (16 if False else 0) < R1_MIN_CYCLES:
-                        d = mfma_cycles - last_operand_use[w]
-                        # the MFMA that read it was issued `d` pipe cycles ago (its own cycles included)
-                        if d < R1_MIN_CYCLES:
-                            errs.append(f"{path} loop {lab} R1: {ln!r} rewrites {w[0]}{w[1]} {d} matrix-pipe cycles "
-                                        f"after an MFMA read it (< {R1_MIN_CYCLES})")
-                            break
+                    # the MFMA that read it was issued `d` pipe cycles ago (its own cycles included)
+                    d = mfma_cycles - last_operand_use[w] if w in last_operand_use else R1_MIN_CYCLES
+                    if d < R1_MIN_CYCLES:
+                        errs.append(f"{path} loop {lab} R1: {ln!r} rewrites {w[0]}{w[1]} {d} matrix-pipe cycles "
+                                    f"after an MFMA read it (< {R1_MIN_CYCLES})")
+                        break
             # R2: rewriting an address register of a queued memory instruction
             for (cnt0, regs0, txt) in queued:
                 if mfma_count - cnt0 < R2_MIN_MFMAS and any(w in regs0 for w in written):

@@ -323,7 +323,7 @@ def iteration(cnt, out, cur, prev, p_cur, p_prev, label):
         # blocks of parity p
         want = 0 if label == "A" else 1
         out.append(f"s_cmp_eq_u32 s{S_PH}, {want}")
-        out.append(f"s_cbranch_scc1 7{label}1f" if False else f"s_cbranch_scc1 {7 if label == 'A' else 8}f")
+        out.append(f"s_cbranch_scc1 {7 if label == 'A' else 8}f")
         out.append("s_setprio 0")
         out.append(f"s_branch {5 if label == 'A' else 6}f")
         out.append(f"{7 if label == 'A' else 8}:")
