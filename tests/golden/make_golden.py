@@ -45,6 +45,19 @@ def main():
     y, n = run(oracle.Chirp(cfg["rate"], cfg["freq"], cfg["chirp_f"], cfg["swipe_s"], cfg["chirp_t"],
                             cfg["decim"], cfg["buffer_len"]), x, cfg["buffer_len"])
     np.savez(os.path.join(HERE, "chirp.npz"), config=json.dumps(cfg), x=x, y=y, lengths=n)
+    # NOISE (full spectrum): every bin of nfft = 12, carry as in TONES (round 2; drawn after the
+    # three above so that those stay byte-identical)
+    cfg = dict(fft_tones=12, pf_average=3, buffer_len=100)
+    x = crandn(rng, 5 * cfg["buffer_len"])
+    y, n = run(oracle.Noise(cfg["fft_tones"], cfg["pf_average"], cfg["buffer_len"]), x, cfg["buffer_len"])
+    np.savez(os.path.join(HERE, "noise.npz"), config=json.dumps(cfg), x=x, y=y, lengths=n)
+    # TX tone comb: 0 Hz and f = +rate dropped, f = -rate is DC, last duplicate wins; three
+    # buffers of 400 samples wrap the length-1000 table
+    cfg = dict(rate=1000, buffer_len=400, freq=[100, -250, 0, 77, 100, -1000, 1000, 500, -250, -1],
+               ampl=[0.1, 0.2, 0.3, 0.05, 0.4, 0.07, 0.9, 0.11, 0.6, 0.02])
+    y = np.concatenate([oracle.tone_gen(cfg["freq"], cfg["ampl"], cfg["rate"], (c * cfg["buffer_len"]) % cfg["rate"],
+                                        cfg["buffer_len"]) for c in range(3)])
+    np.savez(os.path.join(HERE, "tonegen.npz"), config=json.dumps(cfg), y=y)
     print("golden vectors written to", HERE)
 
 

@@ -99,7 +99,7 @@ def mfma_engine(request, monkeypatch):
 # ---------------------------------------------------------------------------
 # frozen fixtures
 # ---------------------------------------------------------------------------
-@pytest.mark.parametrize("name", ["direct", "pfb", "chirp"])
+@pytest.mark.parametrize("name", ["direct", "pfb", "chirp", "noise"])
 @pytest.mark.parametrize("entry", ["host", "device"])
 def test_golden_fixture(cuda_device, gsdr_lib, name, entry, engine):
     g = np.load(os.path.join(HERE, "golden", f"{name}.npz"), allow_pickle=False)
@@ -111,6 +111,12 @@ def test_golden_fixture(cuda_device, gsdr_lib, name, entry, engine):
     elif name == "pfb":
         dem = make_pfb(cfg["freq"], cfg["rate"], cfg["fft_tones"], cfg["pf_average"], L)
         nch = len(cfg["freq"])
+    elif name == "noise":
+        import gpu_sdr_amd as g_
+        dem = g_.RX_buffer_demodulator(g_.param(mode="RX", rate=1200, buffer_len=L, decim=0, pf_average=cfg["pf_average"],
+                                                fft_tones=cfg["fft_tones"], freq=[0], wave_type=[g_.w_type.NOISE]),
+                                       device_index=0)
+        nch = cfg["fft_tones"]
     else:
         dem = make_chirp(cfg["rate"], cfg["freq"], cfg["chirp_f"], cfg["swipe_s"], cfg["chirp_t"], cfg["decim"], L)
         nch = 1
@@ -1291,3 +1297,23 @@ def test_native_library_is_the_one_loaded(cuda_device, gsdr_lib):
     """Guards against a silent fallback: the in-tree libgsdr.so must be mapped."""
     maps = open("/proc/self/maps").read()
     assert "gpu_sdr_amd/libgsdr.so" in maps
+
+
+def test_describe_reports_the_engine_that_ran(cuda_device, gsdr_lib, monkeypatch):
+    """gsdr_demod_describe: the kernel of the last launch, the pipeline streams, the build, and every
+    GSDR_* variable of the process (bench.py prints it into its line)."""
+    import torch
+    monkeypatch.setenv("GSDR_MFMA_PREC", "0")
+    rng = np.random.default_rng(5)
+    dem = make_direct([1000, -2000, 3000], 1_000_000, 100, 4, 50_000)
+    d0 = dem.describe()
+    assert d0["mode"] == "DIRECT" and d0["timing_build"] == 0 and d0["channels"] == 3
+    assert d0["env"].get("GSDR_MFMA_PREC") == "0"
+    x = torch.from_numpy(crandn(rng, 50_000)).to(cuda_device)
+    out = torch.empty(dem.out_capacity, dtype=torch.complex64, device=cuda_device)
+    dem.process_device(x, out)
+    torch.cuda.synchronize()
+    d1 = dem.describe()
+    assert d1["kernel"] == dem.kernel_name == "ddc_mfma_ring16_kernel" and d1["row_tiles_per_workgroup"] == 1
+    assert "timing_build 0" in gsdr_lib.gsdr_build_info().decode()
+    dem.close()
