@@ -94,7 +94,6 @@ struct MfmaLaunch {
     const unsigned *fmod;      // [NT32*32]
     const unsigned *maxbits;   // [slots][16] absmax slots (16 partial maxima each)
     float2 *out;
-    float2 *carry_out;         // AsmRingDirect: receives x[nx - carry_len .. nx); `head` is the carry read
     const uint4 *img;          // AsmRing16P: [ngt][nhi] pre-converted ring-slot images of 8 KiB (ddc_convert_kernel)
     MfmaShape sh;
 };
@@ -114,10 +113,10 @@ hipError_t launch_absmax(const float2 *x, long long n, unsigned *slots, int cur,
                          float2 *head_cur, long long head_n, float2 *head_next, int carry_len,
                          float2 *tail, long long tail0, hipStream_t st, const float2 *extra_src = nullptr,
                          float2 *extra_dst = nullptr, long long extra_n = 0);
-// AsmRing: assembly main loop, operand shared through an LDS ring (production);
-// AsmSolo: assembly main loop, every wave converts its own operand; Cxx: compiler-scheduled
+// AsmRing16 / AsmRing16P / AsmRing16W8: assembly main loops on the 16x16x32 MFMA (production, pre-converted
+// operands, eight-wave workgroups); AsmRing: round 1's loop on the 32x32x16 MFMA; Cxx: compiler-scheduled
 // (TT, PK, W apply to it only; the assembly kernels are TT = 1, PK = 32, W = 4).
-enum class MfmaKernel { AsmRing, AsmSolo, Cxx, AsmRingDirect, AsmRing16, AsmRing16W8, AsmRing16P };
+enum class MfmaKernel { AsmRing, Cxx, AsmRing16, AsmRing16W8, AsmRing16P };
 hipError_t launch_ddc_mfma(MfmaKernel kind, int TT, int PK, int W, const MfmaLaunch &a, hipStream_t st);
 const char *ddc_mfma_kernel_name(MfmaKernel kind);
 

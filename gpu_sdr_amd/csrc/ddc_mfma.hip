@@ -23,25 +23,30 @@
 // four waves of a workgroup take four tone groups of the same rows, and workgroups of
 // the same rows sit on one XCD.
 //
-// Three kernels, one algorithm (all parity-tested, tests/test_gpu_parity.py):
-//   ddc_mfma_ring_kernel  production: assembly main loop (tools/gen_ddc_mfma_ring.py),
-//                         converted A operand shared by the four waves through an LDS ring
-//   ddc_mfma_asm_kernel   assembly main loop (tools/gen_ddc_mfma.py), every wave converts
-//                         its own operand: no ring, no barrier in the loop (GSDR_MFMA_ASM=1)
-//   ddc_mfma_kernel       C++, compiler-scheduled, phases pinned with sched_barrier
-//                         (GSDR_MFMA_ASM=0; also windows too long for the assembly kernels)
+// One algorithm, five kernels (all parity-tested, tests/test_gpu_parity.py):
+//   ddc_mfma_ring16_kernel    production: assembly main loop on v_mfma_f32_16x16x32_f16
+//                             (tools/gen_ddc_mfma_ring16.py), converted A operand shared by the four
+//                             waves through an LDS ring
+//   ddc_mfma_ring16p_kernel   the same loop fed with operands converted once per buffer by
+//                             ddc_convert_kernel (tools/gen_ddc_mfma_ring16p.py): long launches, streams
+//   ddc_mfma_ring16w8_kernel  the same loop for workgroups of eight waves
+//                             (tools/gen_ddc_mfma_ring16w8.py): single launches of one round
+//   ddc_mfma_ring_kernel      round 1's production kernel, the ring loop on v_mfma_f32_32x32x16_f16
+//                             (tools/gen_ddc_mfma_ring.py; GSDR_MFMA_ASM=2)
+//   ddc_mfma_kernel           C++, compiler-scheduled, phases pinned with sched_barrier
+//                             (GSDR_MFMA_ASM=0): the readable statement of the algorithm
+// (Two further assembly variants of round 1 -- every wave converting its own operand, and a
+//  single-launch loop reading buffer and carry in place -- were measured dead ends and are gone.)
 #include <cmath>
 #include <cstdlib>
 #include <type_traits>
 #include <vector>
 
 #include "ddc_device.h"
-#include "ddc_mfma_gen.h"
 #include "ddc_mfma_ring_gen.h"
 #include "ddc_mfma_ring16_gen.h"
 #include "ddc_mfma_ring16w8_gen.h"
 #include "ddc_mfma_ring16p_gen.h"
-#include "ddc_mfma_ringd_gen.h"
 
 namespace gsdr {
 
@@ -354,109 +359,6 @@ __global__ __launch_bounds__(64 * W, TT == 1 ? 2 : 1) void ddc_mfma_kernel(const
     }
     if (!active) return;
     store_rows<TT>(a, gt, n0, hh, invS, accr, acci);
-}
-
-// The same arithmetic with the main loop in assembly (tools/gen_ddc_mfma.py): one
-// tone tile per wave, four independent waves per workgroup (no LDS ring, no barrier
-// in the loop: every wave converts its own A operand; the workgroup shares only the
-// table of scaled taps in LDS and, through the L1, the input).  Everything around
-// the loop -- work split, scale, addresses, the stores -- is C++.
-constexpr int kAsmTaps = 10240;   // LDS table of the scaled taps, 40 KiB
-
-// (no packed FP32 in the whole kernel: rule R3 of the generator applies to the
-// compiler-generated code around the loop as well)
-__global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops"))) void ddc_mfma_asm_kernel(
-    const MfmaLaunch a) {
-    constexpr int KS = 4, W = 4;
-    __shared__ float table[kAsmTaps];   // taps while the loop runs, then the accumulators (4 x 8 KiB)
-    const MfmaShape &sh = a.sh;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int r = lane & 31, hh = lane >> 5;
-    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-    const int gt = (q / sh.ntq) * 8 + xcd;
-    if (gt >= sh.ngt) return;
-    const int tg_raw = (q % sh.ntq) * W + wave;
-    const bool active = tg_raw < sh.ntg;      // idle waves run the loop too (they meet the end barrier)
-    const int tg = active ? tg_raw : sh.ntg - 1;
-
-    const unsigned mb = slot_max(a.maxbits, sh.slot_cur, sh.slot_prev);
-    int se = 140 - (int)((mb >> 23) & 0xffu);
-    se = se > 100 ? 100 : (se < -100 ? -100 : se);
-    const float S = bits_to_float((unsigned)(127 + se) << 23);
-    const float invS = bits_to_float((unsigned)(127 - se) << 23) * sh.unscale;
-
-    // scaled taps with zeros behind them: the loop's look-ahead reads up to three
-    // k-steps past the window
-    const int nhi = (sh.nk8 + KS - 1) / KS;
-    const int ntaps = nhi * 32, nfill = ntaps + 128;
-    {
-        // every thread takes 4 taps per pass (16-byte loads, all issued before the first store)
-        constexpr int kPass = 10;                           // 10 * 1024 >= kAsmTaps
-        float4v t4[kPass];
-#pragma unroll
-        for (int k = 0; k < kPass; ++k) {
-            const int i = (k * 256 + (int)threadIdx.x) * 4;
-            t4[k] = i < ntaps ? *reinterpret_cast<const float4v *>(a.taps + i) : float4v{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int k = 0; k < kPass; ++k) {
-            const int i = (k * 256 + (int)threadIdx.x) * 4;
-            if (i < nfill) *reinterpret_cast<float4v *>(table + i) = t4[k] * S;
-        }
-    }
-    workgroup_sync();
-
-    // scalar bases + per-lane non-negative byte offsets (global_load ..., voffset, s[base])
-    const int o = gt * 32 + r;
-    const int oc = o < sh.nout ? o : sh.nout - 1;
-    const float2 *xbase;           // sample s of this tile's rows lives at xbase[s + xshift]
-    long long xshift;
-    if (gt == 0) {
-        xbase = a.head;
-        xshift = sh.carry_len;
-    } else if (gt == sh.ngt - 1) {
-        xbase = a.tail;
-        xshift = -sh.tail0;
-    } else {
-        xbase = a.x;
-        xshift = 0;
-    }
-    const unsigned xo = (unsigned)((((long long)(oc + sh.woff) * sh.M + xshift) + 4 * hh) * 8);
-    const int Np = sh.NT32 * 32;
-    const int n0 = tg * 32 + r;
-    const unsigned po = (unsigned)n0 * 8u;
-    const unsigned bo = (unsigned)tg * (KS * 4 * 1024u) + (unsigned)lane * 16u;
-    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char *)table;
-    const unsigned tb = lds_base + 16u * (unsigned)hh;
-    const unsigned accaddr = lds_base + (unsigned)wave * 8192u + (unsigned)lane * 16u;
-    const unsigned long long xb = (unsigned long long)xbase, ppb = (unsigned long long)a.ptab,
-                             bfb = (unsigned long long)a.bfrag;
-    asm volatile(GSDR_MFMA_ASM_TEXT
-                 :
-                 : [xo] "v"(xo), [tb] "v"(tb), [po] "v"(po), [bo] "v"(bo), [accaddr] "v"(accaddr),
-                   [xb_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)xb)),
-                   [xb_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(xb >> 32))),
-                   [pp_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)ppb)),
-                   [pp_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(ppb >> 32))),
-                   [bf_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)bfb)),
-                   [bf_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(bfb >> 32))),
-                   [pstride] "s"(__builtin_amdgcn_readfirstlane((int)((unsigned)Np * 8u))),
-                   [nhi] "s"(__builtin_amdgcn_readfirstlane(nhi))
-                 : GSDR_MFMA_ASM_CLOBBERS);
-    if (!active) return;
-    float16v accr[1], acci[1];
-    const float4v *acc = reinterpret_cast<const float4v *>(table) + wave * 512 + lane;
-#pragma unroll
-    for (int qd = 0; qd < 4; ++qd) {
-        const float4v vr = acc[qd * 64], vi = acc[(qd + 4) * 64];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            accr[0][qd * 4 + j] = vr[j];
-            acci[0][qd * 4 + j] = vi[j];
-        }
-    }
-    store_rows<1>(a, gt, n0, hh, invS, accr, acci);
 }
 
 // Variant with the converted A operand shared through an LDS ring
@@ -935,129 +837,6 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
     ring16p_tile(a, lds, gt0, 1, se, tg, wave, active);
 }
 
-// The ring kernel without its staging pass: ONE launch per buffer.  The loop reads the
-// caller's buffer and the carry directly (tools/gen_ddc_mfma_ring.py --direct: two
-// loads under complementary EXEC masks, clamped at the end of the buffer, where only
-// zero taps are met); the workgroup takes the maximum of exactly the samples its rows
-// read (its own power-of-two scale instead of one per buffer), and one workgroup copies
-// the last carry_len samples to the carry of the next call.  Needs M % 4 == 0: a group
-// of four samples then lies entirely in the carry or entirely in the buffer.
-__global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops"))) void ddc_mfma_ringd_kernel(
-    const MfmaLaunch a) {
-    constexpr int KS = 4, W = 4;
-    __shared__ uint4 lds[2048];
-    __shared__ unsigned wmax[W];
-    static_assert(sizeof(uint4) * 2048 >= GSDR_MFMA_RINGD_BYTES, "ring fits");
-    const MfmaShape &sh = a.sh;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int r = lane & 31, hh = lane >> 5;
-    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-    const int gt = (q / sh.ntq) * 8 + xcd;
-    if (gt >= sh.ngt) return;
-    const int tg_raw = (q % sh.ntq) * W + wave;
-    const bool active = tg_raw < sh.ntg;
-    const int tg = active ? tg_raw : sh.ntg - 1;
-    const int nhi = timing_one_block(sh) ? 1 : (sh.nk8 + KS - 1) / KS;
-    const int L = (int)sh.nx, cl = sh.carry_len;
-
-    if (gt == sh.ngt - 1 && q % sh.ntq == 0) {
-        const float2 *src = a.x + (L - cl);
-        for (int i = (int)threadIdx.x; i < cl; i += 256) a.carry_out[i] = src[i];
-    }
-
-    // max |component| over the samples of this row tile: [lo, hi) clipped to the buffer
-    const int o_last = gt * 32 + 31 < sh.nout ? gt * 32 + 31 : sh.nout - 1;
-    const int lo = (gt * 32 + sh.woff) * sh.M;
-    int hi = (o_last + sh.woff) * sh.M + nhi * 32;
-    hi = hi < L ? hi : L;
-    // (four groups in flight per thread: indices past the end are clamped, a sample seen
-    // twice does not change a maximum)
-    unsigned m = 0;
-    for (int sb = lo + 4 * (int)threadIdx.x; sb < hi; sb += 4096) {
-        float4u v[8];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            int s = sb + 1024 * u;
-            s = s < hi - 4 ? s : hi - 4;
-            const float2 *p = s < 0 ? a.head + (s + cl) : a.x + s;
-            v[2 * u] = reinterpret_cast<const float4u *>(p)[0];
-            v[2 * u + 1] = reinterpret_cast<const float4u *>(p)[1];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const unsigned b = float_to_bits(v[u][j]) & 0x7fffffffu;
-                m = m > b ? m : b;
-            }
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const unsigned t = lane_xor(m, d);
-        m = m > t ? m : t;
-    }
-    if (lane == 0) wmax[wave] = m;
-    workgroup_sync();
-    unsigned mb = wmax[0];
-#pragma unroll
-    for (int i = 1; i < W; ++i) mb = mb > wmax[i] ? mb : wmax[i];
-    mb = (unsigned)__builtin_amdgcn_readfirstlane((int)mb);
-    int se = 140 - (int)((mb >> 23) & 0xffu);
-    se = se > 100 ? 100 : (se < -100 ? -100 : se);
-    const float S = bits_to_float((unsigned)(127 + se) << 23);
-    const float invS = bits_to_float((unsigned)(127 - se) << 23) * sh.unscale;
-
-    const int o = gt * 32 + r;
-    const int oc = o < sh.nout ? o : sh.nout - 1;
-    // index of the first sample group this lane loads: k-step `wave` of block 0
-    const int s0 = (oc + sh.woff) * sh.M + 4 * hh + 8 * wave;
-    const unsigned to = (unsigned)((4 * hh + 8 * wave) * 4);
-    const int Np = sh.NT32 * 32;
-    const int n0 = tg * 32 + r;
-    const unsigned po = (unsigned)n0 * 8u;
-    const unsigned bo = (unsigned)tg * (KS * 4 * 1024u) + (unsigned)lane * 16u;
-    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char *)lds;
-    const unsigned lane16 = lds_base + (unsigned)lane * 16u;
-    const unsigned wr16 = lane16 + (unsigned)wave * 2048u;
-    const unsigned accaddr = lds_base + (unsigned)wave * 8192u + (unsigned)lane * 16u;
-    const unsigned long long xb = (unsigned long long)a.x, cb = (unsigned long long)a.head,
-                             tpb = (unsigned long long)a.taps, ppb = (unsigned long long)a.ptab,
-                             bfb = (unsigned long long)a.bfrag;
-    asm volatile(GSDR_MFMA_RINGD_TEXT
-                 :
-                 : [s0] "v"(s0), [to] "v"(to), [po] "v"(po), [bo] "v"(bo), [lane16] "v"(lane16), [wr16] "v"(wr16),
-                   [accaddr] "v"(accaddr), [xb_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)xb)),
-                   [xb_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(xb >> 32))),
-                   [cb_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)cb)),
-                   [cb_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(cb >> 32))),
-                   [smax] "s"(__builtin_amdgcn_readfirstlane(L - 4)),
-                   [cl8] "s"(__builtin_amdgcn_readfirstlane(cl * 8)),
-                   [tp_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)tpb)),
-                   [tp_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(tpb >> 32))),
-                   [pp_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)ppb)),
-                   [pp_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(ppb >> 32))),
-                   [bf_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)bfb)),
-                   [bf_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(bfb >> 32))),
-                   [pstride] "s"(__builtin_amdgcn_readfirstlane((int)((unsigned)Np * 8u))),
-                   [nhi] "s"(__builtin_amdgcn_readfirstlane(nhi)),
-                   [scale] "v"(S)
-                 : GSDR_MFMA_RINGD_CLOBBERS);
-    if (!active || timing_no_stores(sh)) return;
-    float16v accr[1], acci[1];
-    const float4v *acc = reinterpret_cast<const float4v *>(lds) + wave * 512 + lane;
-#pragma unroll
-    for (int qd = 0; qd < 4; ++qd) {
-        const float4v vr = acc[qd * 64], vi = acc[(qd + 4) * 64];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            accr[0][qd * 4 + j] = vr[j];
-            acci[0][qd * 4 + j] = vi[j];
-        }
-    }
-    store_tile(a, gt, n0, hh, invS, tile_phasor(a, gt, a.fmod[n0]), accr[0], acci[0]);
-}
-
 // One pass over the new buffer x[0..n):
 //   * max |component| as float bits -> atomicMax(slots[cur]); slots[next] = 0;
 //   * head_cur[carry_len + i] = x[i] for i < head_n (row tile 0 reads [carry | x) there);
@@ -1345,18 +1124,6 @@ hipError_t launch_ddc_mfma(MfmaKernel kind, int TT, int PK, int W, const MfmaLau
     if (a.x != a.tail && sh.ngt > 2 && (long long)(32 * (sh.ngt - 1) - 1 + sh.woff) * sh.M + reach > sh.nx)
         return hipErrorInvalidValue;
     if (sh.ngt > 1 && (long long)(32 * (sh.ngt - 1) + sh.woff) * sh.M < sh.tail0) return hipErrorInvalidValue;
-    if (kind == MfmaKernel::AsmRingDirect) {
-        // one launch: buffer and carry are read in place, clamped at nx - 4
-        if (TT != 1 || PK != 32 || W != 4 || sh.M % 4 != 0 || sh.nx < 4 || sh.nx % 4 != 0 ||
-            sh.nx > 0x0fffffffLL || sh.carry_len != -sh.woff * sh.M || sh.carry_len > sh.nx ||
-            sh.nx != (long long)sh.nout * sh.M || !a.carry_out || a.carry_out == a.head)
-            return hipErrorInvalidValue;
-        const int gt8 = (sh.ngt + 7) / 8;
-        const long long grid = (long long)gt8 * 8 * sh.ntq;
-        if (grid < 1 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(ddc_mfma_ringd_kernel, dim3((unsigned)grid), dim3(256), 0, st, a);
-        return hipGetLastError();
-    }
     if (kind == MfmaKernel::AsmRing16P) {
         // the conversion pass, then the loop that copies its images (a.img: ngt * nhi images of 8 KiB)
         if (TT != 1 || PK != 32 || W != 4 || !a.img) return hipErrorInvalidValue;
@@ -1397,15 +1164,6 @@ hipError_t launch_ddc_mfma(MfmaKernel kind, int TT, int PK, int W, const MfmaLau
         hipLaunchKernelGGL(ddc_mfma_ring_kernel, dim3((unsigned)grid), dim3(256), 0, st, a);
         return hipGetLastError();
     }
-    if (kind == MfmaKernel::AsmSolo) {
-        if (TT != 1 || PK != 32 || W != 4 || ((sh.nk8 + 3) / 4) * 32 + 128 > kAsmTaps)
-            return hipErrorInvalidValue;
-        const int gt8 = (sh.ngt + 7) / 8;
-        const long long grid = (long long)gt8 * 8 * sh.ntq;
-        if (grid < 1 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(ddc_mfma_asm_kernel, dim3((unsigned)grid), dim3(256), 0, st, a);
-        return hipGetLastError();
-    }
     if (TT == 2 && PK == 32) return launch_tp<2, 32>(W, a, st);
     if (TT == 1 && PK == 32) return launch_tp<1, 32>(W, a, st);
     if (TT == 2 && PK == 16) return launch_tp<2, 16>(W, a, st);
@@ -1414,7 +1172,7 @@ hipError_t launch_ddc_mfma(MfmaKernel kind, int TT, int PK, int W, const MfmaLau
 }
 
 const char *ddc_mfma_kernel_name(MfmaKernel kind) {
-    return kind == MfmaKernel::AsmRing16P ? "ddc_mfma_ring16p_kernel" : kind == MfmaKernel::AsmRing16W8 ? "ddc_mfma_ring16w8_kernel" : kind == MfmaKernel::AsmRing16 ? "ddc_mfma_ring16_kernel" : kind == MfmaKernel::AsmRingDirect ? "ddc_mfma_ringd_kernel" : kind == MfmaKernel::AsmRing ? "ddc_mfma_ring_kernel" : kind == MfmaKernel::AsmSolo ? "ddc_mfma_asm_kernel" : "ddc_mfma_kernel";
+    return kind == MfmaKernel::AsmRing16P ? "ddc_mfma_ring16p_kernel" : kind == MfmaKernel::AsmRing16W8 ? "ddc_mfma_ring16w8_kernel" : kind == MfmaKernel::AsmRing16 ? "ddc_mfma_ring16_kernel" : kind == MfmaKernel::AsmRing ? "ddc_mfma_ring_kernel" : "ddc_mfma_kernel";
 }
 
 }  // namespace gsdr

@@ -384,22 +384,13 @@ int setup_mfma(gsdr_demod *h, bool direct, const std::vector<long long> &tone) {
     // the assembly main loops exist for the default shape only; GSDR_MFMA_ASM: 4 = LDS operand ring
     // on v_mfma_f32_16x16x32_f16 (default since round 2: the same cycles per FLOP for less energy,
     // +7 % on C3 under the power cap), 5 = that loop for workgroups of eight waves, 2 = the ring on
-    // v_mfma_f32_32x32x16_f16 (round 1's production kernel), 1 = ring-less loop (needs the scaled
-    // taps in its 40 KiB LDS table: 10240 - 128 taps), 0 = the compiler-scheduled kernel (A/B runs, tests)
+    // v_mfma_f32_32x32x16_f16 (round 1's production kernel), 0 = the compiler-scheduled kernel (A/B runs, tests)
     const int asm_kind = env_int("GSDR_MFMA_ASM", 4);
     const bool asm_shape = h->mf_TT == 1 && h->mf_PK == 32 && h->mf_W == 4;
     h->mf_kind = gsdr::MfmaKernel::Cxx;
     if (asm_kind == 2 && asm_shape) h->mf_kind = gsdr::MfmaKernel::AsmRing;
-    if (asm_kind == 1 && asm_shape && ((M * F + 31) / 32) * 32 + 128 <= 10240) h->mf_kind = gsdr::MfmaKernel::AsmSolo;
-    // 3 = the ring kernel reading buffer and carry in place: one launch per buffer (DIRECT,
-    // M % 4 == 0; other shapes fall back to 2)
-    // 4 = the ring loop on v_mfma_f32_16x16x32_f16 (tools/gen_ddc_mfma_ring16.py)
-    if (asm_kind == 4 && asm_shape) h->mf_kind = gsdr::MfmaKernel::AsmRing16;
-    // 5 = the same loop for workgroups of eight waves (tools/gen_ddc_mfma_ring16w8.py)
-    if (asm_kind == 5 && asm_shape) h->mf_kind = gsdr::MfmaKernel::AsmRing16W8;
-    if (asm_kind == 3 && asm_shape)
-        h->mf_kind = direct && M % 4 == 0 && h->L < 0x10000000LL ? gsdr::MfmaKernel::AsmRingDirect
-                                                                  : gsdr::MfmaKernel::AsmRing;
+    if (asm_kind == 4 && asm_shape) h->mf_kind = gsdr::MfmaKernel::AsmRing16;      // tools/gen_ddc_mfma_ring16.py
+    if (asm_kind == 5 && asm_shape) h->mf_kind = gsdr::MfmaKernel::AsmRing16W8;    // tools/gen_ddc_mfma_ring16w8.py
     gsdr::MfmaPlan pl{};
     pl.TT = h->mf_TT;
     pl.PK = h->mf_PK;
@@ -655,12 +646,6 @@ int enqueue_mfma(gsdr_demod *h, const float2 *in, float2 *raw, long long raw_new
                                       nullptr, h->L, st, spare_src, raw, spare_n));
         if (h->pipe_overlap) HIPCHK(h, hipEventRecord(h->ev_abs[h->pipe_seq % 4], st));
         a.x = a.head = a.tail = raw;
-        a.sh.tail0 = 0;
-    } else if (h->mf_kind == gsdr::MfmaKernel::AsmRingDirect) {
-        // single launch: d_head[] only hold the carry (their first carry_len samples)
-        a.x = a.tail = in;
-        a.head = h->d_head[hs];
-        a.carry_out = h->d_head[hs_next];
         a.sh.tail0 = 0;
     } else {
         const int cl = a.sh.carry_len;
@@ -1309,7 +1294,7 @@ static int pipeline_init_parts(gsdr_demod *h) {
 //     slot j and clears slot j+1 -- disjoint modulo kStageSets = S+1 and kScaleSlots = S+2.
 // Every other mode keeps the one compute stream.  GSDR_PIPE_OVERLAP=0 does so for DIRECT too.
 static int pipeline_compute(gsdr_demod *h, gsdr_demod::Slot &sl, hipEvent_t up, const float2 *in, float2 *out) {
-    const bool ddc = (h->mode == GSDR_DIRECT && h->decim > 0 && h->mf_kind != gsdr::MfmaKernel::AsmRingDirect) ||
+    const bool ddc = (h->mode == GSDR_DIRECT && h->decim > 0) ||
                      h->mode == GSDR_TONES || h->mode == GSDR_NOISE;
     const bool overlap = env_int("GSDR_PIPE_OVERLAP", 1) != 0 && h->mfma && ddc;
     hipStream_t cs = overlap ? h->s_main[h->pipe_seq % (unsigned)h->pipe_streams] : h->stream;

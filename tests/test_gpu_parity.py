@@ -74,24 +74,24 @@ def make_chirp(rate, f0, f1, steps, t, decim, L):
     return g.RX_buffer_demodulator(p, device_index=0)
 
 
-@pytest.fixture(params=["flat", "mfma", "mfma1", "mfma_rt2", "mfma16", "mfma16w8", "mfma16p"])
+@pytest.fixture(params=["flat", "mfma", "mfma_rt2", "mfma16", "mfma16w8", "mfma16p"])
 def engine(request, monkeypatch):
-    """Runs a test once per DDC engine: packed-FP32 VALU kernel, matrix-core kernel behind
-    its staging pass, matrix-core kernel reading buffer and carry in place (one launch;
-    shapes it does not take -- M % 4 != 0, TONES -- fall back to the staged one)."""
+    """Runs a test once per DDC engine: packed-FP32 VALU kernel; round 1's matrix-core kernel (32x32x16
+    MFMA; one / two row tiles per workgroup); the 16x16x32 ring loop, its eight-wave build and its
+    pre-converted-operand build."""
     monkeypatch.setenv("GSDR_DDC_MFMA", "0" if request.param == "flat" else "1")
-    monkeypatch.setenv("GSDR_MFMA_ASM", {"mfma1": "3", "mfma16": "4", "mfma16w8": "5", "mfma16p": "4"}.get(request.param, "2"))
+    monkeypatch.setenv("GSDR_MFMA_ASM", {"mfma16": "4", "mfma16w8": "5", "mfma16p": "4"}.get(request.param, "2"))
     monkeypatch.setenv("GSDR_MFMA_PREC", "1" if request.param == "mfma16p" else "0")
     monkeypatch.setenv("GSDR_MFMA_RT", "2" if request.param == "mfma_rt2" else "0")
     return request.param
 
 
-@pytest.fixture(params=["staged", "direct", "x16", "x16w8", "x16p"])
+@pytest.fixture(params=["staged", "x16", "x16w8", "x16p"])
 def mfma_engine(request, monkeypatch):
-    """Matrix-core DDC behind its staging pass / reading buffer and carry in place / the ring
-    loop on the 16x16x32 MFMA shape."""
+    """Matrix-core DDC: round 1's loop on the 32x32x16 MFMA / the ring loop on the 16x16x32 shape /
+    its eight-wave build / its pre-converted-operand build."""
     monkeypatch.setenv("GSDR_DDC_MFMA", "1")
-    monkeypatch.setenv("GSDR_MFMA_ASM", {"direct": "3", "x16": "4", "x16w8": "5", "x16p": "4"}.get(request.param, "2"))
+    monkeypatch.setenv("GSDR_MFMA_ASM", {"x16": "4", "x16w8": "5", "x16p": "4"}.get(request.param, "2"))
     monkeypatch.setenv("GSDR_MFMA_PREC", "1" if request.param == "x16p" else "0")
     return request.param
 
@@ -152,7 +152,7 @@ DIRECT_CASES = [
 
 @pytest.mark.parametrize("case", DIRECT_CASES, ids=lambda c: "N%d_M%d_F%d_L%d" % (c[0], c[2], c[3], c[4]))
 @pytest.mark.parametrize("impl", ["flat", "flat12", "flat16", "flat20", "simple16", "simple32",
-                                  "mfma", "mfma_rt2", "mfma16", "mfma16_rt2", "mfma16w8", "mfma16p", "mfma_direct", "mfma_solo", "mfma_c", "mfma_t2",
+                                  "mfma", "mfma_rt2", "mfma16", "mfma16_rt2", "mfma16w8", "mfma16p", "mfma_c", "mfma_t2",
                                   "mfma_w2", "mfma_pk16"])
 def test_direct_parity(cuda_device, gsdr_lib, oracle_mod, monkeypatch, case, impl):
     """flat* = ddc_flat_kernel (packed FP32; sub-block length auto / forced),
@@ -167,9 +167,6 @@ def test_direct_parity(cuda_device, gsdr_lib, oracle_mod, monkeypatch, case, imp
     waves of a SIMD barrier-coupled partners, conversion shared by eight waves),
     mfma16p = ddc_convert_kernel + ddc_mfma_ring16p_kernel (the operand converted once per buffer, the loop
     copies 8-KiB images into its ring by LDS-DMA: the path of launches of many rounds, forced here),
-    mfma_direct = ddc_mfma_ringd_kernel (the same loop reading buffer and carry in place: one
-    launch per buffer, one scale per workgroup; M % 4 == 0, other shapes run the staged kernel),
-    mfma_solo = ddc_mfma_asm_kernel (assembly main loop, every wave converts its own operand),
     mfma_c* = ddc_mfma_kernel (same algorithm, compiler-scheduled; tone tiles per wave 1/2,
     waves per workgroup 4/2, phasor block 32/16)."""
     N, rate, M, F, L, nbuf = case
@@ -185,10 +182,6 @@ def test_direct_parity(cuda_device, gsdr_lib, oracle_mod, monkeypatch, case, imp
             monkeypatch.setenv("GSDR_MFMA_PREC", "1" if impl == "mfma16p" else "0")
             if impl == "mfma16_rt2":
                 monkeypatch.setenv("GSDR_MFMA_RT", "2")
-        if impl == "mfma_direct":
-            monkeypatch.setenv("GSDR_MFMA_ASM", "3")
-        if impl == "mfma_solo":
-            monkeypatch.setenv("GSDR_MFMA_ASM", "1")
         if impl in ("mfma_c", "mfma_t2", "mfma_w2", "mfma_pk16"):
             monkeypatch.setenv("GSDR_MFMA_ASM", "0")
         if "_t" in impl:
@@ -208,8 +201,6 @@ def test_direct_parity(cuda_device, gsdr_lib, oracle_mod, monkeypatch, case, imp
     dem = make_direct(freq, rate, M, F, L)
     ref = oracle_mod.Direct(freq, rate, M, F, L)
     np.testing.assert_array_equal(dem.window(), ref.taps())
-    if impl == "mfma_direct" and dem.kernel_name.startswith("ddc_mfma"):
-        assert dem.kernel_name == ("ddc_mfma_ringd_kernel" if M % 4 == 0 else "ddc_mfma_ring_kernel")
     for c in range(nbuf):
         x = crandn(rng, L)
         y = (run_host if c % 2 else run_device)(dem, x, *(() if c % 2 else (cuda_device,)))

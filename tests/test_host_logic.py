@@ -184,11 +184,9 @@ def test_no_cpu_fallback_in_product():
 
 
 @pytest.mark.parametrize("gen,header", [("gen_ddc_mfma_ring.py", "ddc_mfma_ring_gen.h"),
-                                        ("gen_ddc_mfma_ring.py --direct", "ddc_mfma_ringd_gen.h"),
                                         ("gen_ddc_mfma_ring16.py", "ddc_mfma_ring16_gen.h"),
                                         ("gen_ddc_mfma_ring16w8.py", "ddc_mfma_ring16w8_gen.h"),
                                         ("gen_ddc_mfma_ring16p.py", "ddc_mfma_ring16p_gen.h"),
-                                        ("gen_ddc_mfma.py", "ddc_mfma_gen.h"),
                                         ("gen_ddc_steps.py", "ddc_steps_gen.h")])
 def test_generated_headers_are_current(gen, header):
     """The committed assembly headers are exactly what their generators produce
@@ -207,7 +205,7 @@ def test_generated_headers_are_current(gen, header):
     assert produced == committed
 
 
-RING_HEADERS = ["ddc_mfma_ring_gen.h", "ddc_mfma_ringd_gen.h", "ddc_mfma_ring16_gen.h", "ddc_mfma_ring16w8_gen.h",
+RING_HEADERS = ["ddc_mfma_ring_gen.h", "ddc_mfma_ring16_gen.h", "ddc_mfma_ring16w8_gen.h",
                 "ddc_mfma_ring16p_gen.h"]
 
 

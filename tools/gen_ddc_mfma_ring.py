@@ -1,31 +1,47 @@
 #!/usr/bin/env python3
-"""Generates gpu_sdr_amd/csrc/ddc_mfma_ring_gen.h: main loop of ddc_mfma_ring_kernel
-(gfx950), the variant of tools/gen_ddc_mfma.py in which the four waves of a
+"""Generates gpu_sdr_amd/csrc/ddc_mfma_ring_gen.h: the main loop of ddc_mfma_ring_kernel
+(gfx950) as one inline-asm block with a fixed register map; the four waves of a
 workgroup SHARE the converted A operand through an LDS ring.
 
+Why assembly: the loop's correctness depends on register reuse distances and
+operand forms the compiler does not know about (see "Rules" below, all measured
+on MI355X with scratch/mfma_probe.py), and its speed on an exact MFMA/VALU interleave.
+
+Work of one wave: 32 output rows x 32 tones; every phasor block of 32 samples is
+4 k-steps x 6 MFMAs (v_mfma_f32_32x32x16_f16: Cr/Ci x {hi*Bhi, hi*Blo, lo*Bhi}).
 Each wave converts one k-step of every block (x * taps * S -> fp16 hi/lo, 28 plain
 VALU instructions) into ring slot (b+2)%3 and reads all four k-steps of block b back
-as MFMA operands: a quarter of the global loads and of the conversion work of the
-ring-less loop, at the price of one s_barrier per block and ten LDS instructions
-per wave and block.  The rules R1..R4 of tools/gen_ddc_mfma.py apply; the ring
-address registers and the scalar load bases exist once per iteration parity (R2).
+as MFMA operands: a quarter of the global loads and of the conversion work of a loop
+in which every wave converts for itself (round 1 measured that one: slower), at the
+price of one s_barrier per block and ten LDS instructions per wave and block.  In the
+MFMAs' shadow the wave also applies P*C of the previous block on the VALU (C alternates
+between two register sets, hence the 2x unroll).  All of that is plain (non-packed)
+FP32: tools/ubench_mfma.hip measures that v_pk_fma_f32 / v_pk_mul_f32 do not overlap
+with the f16 MFMA at all (+10 cycles each), while v_fma_f32, v_mul_f32,
+v_cvt_pk_f16_f32 and v_fma_mix_f32 nearly vanish in its shadow at two waves per SIMD
+(6 per MFMA: +7 %).
+
+Rules this file and its descendants (gen_ddc_mfma_ring16*.py) keep -- each one cost a
+debugging session; tools/check_asm_rules.py re-checks R1..R3 on the emitted text:
+  R1  A register that an MFMA reads as A/B operand is not rewritten before twelve
+      further MFMAs have been issued (four operand buffers).  With less distance
+      rows 16..31 of the MFMA came out computed from the new contents.
+  R2  Address, data and scalar-base registers of a memory instruction stay unchanged
+      for two k-steps after it was issued: with two workgroups on a CU they are read
+      late (registers rewritten ~4 MFMAs later gave half of the lanes the new address).
+      The ring address registers and the scalar load bases exist once per iteration parity.
+  R3  No v_pk_*_f32 that broadcasts the HIGH half of a pair written by the packed
+      instruction in front of it (op_sel:[0,1] / [1,..]): it returned a stale value in
+      lanes 48..63 now and then while another wave of the SIMD ran this loop
+      (isolated reproducer: tools/ubench_pk_hazard.hip).  The loop has no packed FP32
+      at all (see above); the kernel around it is compiled without packed FP32.
+  R4  s_waitcnt values come from a model of the counters (class Counters).
 
     python3 tools/gen_ddc_mfma_ring.py > gpu_sdr_amd/csrc/ddc_mfma_ring_gen.h
-    python3 tools/gen_ddc_mfma_ring.py --direct > gpu_sdr_amd/csrc/ddc_mfma_ringd_gen.h
-
---direct: the loop reads the caller's buffer and the carry (the last (F-1)*M samples
-of the previous buffer) itself instead of the head / tail copies a staging kernel
-laid out: one kernel launch per buffer.  Every lane keeps the index s of the sample
-group it loads next; s < 0 is served from the carry, s > L-4 is clamped (those
-samples only ever meet zero taps).  The two sources are two loads under
-complementary EXEC masks; their offsets and the mask exist once per iteration
-parity (R2) and are rewritten only after the previous loads of that parity have
-been waited for.
 """
 import os
 import sys
 
-DIRECT = "--direct" in sys.argv
 # timing-only builds (WRONG results): GEN_ABLATE=rot,prod,lds,gload,bar,bimg drops the rotation
 # FMAs / the conversion arithmetic / the operand reads of the ring / the input loads / the barrier
 # from the loop, the phasor-image loads from the prologue
@@ -47,9 +63,7 @@ PB = (VB + 154, VB + 155)
 V_SC = VB + 156            # S
 # ring addresses, one set per iteration parity (R2)
 ADDR = {"A": (VB + 157, VB + 158, VB + 159), "B": (VB + 160, VB + 161, VB + 162)}
-# --direct: byte offsets of the next sample group into the buffer / into the carry
-OFF = {"A": (VB + 163, VB + 164), "B": (VB + 165, VB + 166)}
-V_LAST = VB + 166 if DIRECT else VB + 162
+V_LAST = VB + 162
 NVGPR_CLOBBER = list(range(VB, V_LAST + 1))
 NAGPR = 64
 
@@ -65,14 +79,7 @@ S_XB = 52      # s[52:53] x base, block 0
 S_TB = 54      # s[54:55] taps base, block 0
 S_BF = 56      # s[56:57] phasor-table images
 S_PSTRIDE = 58
-# --direct
-S_B32 = 59     # 32 * block index of the loads being prepared
-S_SMAX = 72    # L - 4
-S_CL8 = 73     # 8 * carry length
-S_CB = 74      # s[74:75] carry base
-MK = {"A": 80, "B": 82, "C": 84}   # lanes whose group lies in the carry
-S_EXEC = 86    # s[86:87] EXEC on entry
-SGPR_CLOBBER = list(range(36, 88 if DIRECT else 80))
+SGPR_CLOBBER = list(range(36, 80))
 
 
 def vr(base, n=1):
@@ -143,7 +150,7 @@ def rotate_ops(cset, p):
 
 def produce_ops(xa=None, xb=None, hv=None):
     """x (4 complex samples in XA, XB) * taps (HV) * S -> fp16 hi (HI4) and lo (LO4):
-    28 plain VALU instructions (no packed FP32, see tools/gen_ddc_mfma.py)."""
+    28 plain VALU instructions (no packed FP32, see the rules above)."""
     xa, xb, hv = (XA if xa is None else xa), (XB if xb is None else xb), (HV if hv is None else hv)
     ops = []
     for j in range(4):
@@ -167,21 +174,6 @@ def gload_ops(cnt, out, par, xa=None, xb=None, hv=None, off=None):
     xa, xb, hv = (XA if xa is None else xa), (XB if xb is None else xb), (HV if hv is None else hv)
     out.append(f"global_load_dwordx4 {vr(hv, 4)}, %[to], s[{S_T}:{S_T + 1}]")
     cnt.issue_vm("hv")
-    if DIRECT:
-        oi, oc = off if off is not None else OFF[par]
-        mk = MK[par]
-        out.append(f"s_andn2_b64 exec, exec, s[{mk}:{mk + 1}]")
-        out.append(f"global_load_dwordx4 {vr(xa, 4)}, {vr(oi)}, s[{S_XB}:{S_XB + 1}]")
-        cnt.issue_vm("xa")
-        out.append(f"global_load_dwordx4 {vr(xb, 4)}, {vr(oi)}, s[{S_XB}:{S_XB + 1}] offset:16")
-        cnt.issue_vm("xb")
-        out.append(f"s_and_b64 exec, s[{S_EXEC}:{S_EXEC + 1}], s[{mk}:{mk + 1}]")
-        out.append(f"global_load_dwordx4 {vr(xa, 4)}, {vr(oc)}, s[{S_CB}:{S_CB + 1}]")
-        cnt.issue_vm("xa")
-        out.append(f"global_load_dwordx4 {vr(xb, 4)}, {vr(oc)}, s[{S_CB}:{S_CB + 1}] offset:16")
-        cnt.issue_vm("xb")
-        out.append(f"s_mov_b64 exec, s[{S_EXEC}:{S_EXEC + 1}]")
-        return
     out.append(f"global_load_dwordx4 {vr(xa, 4)}, %[xo], s[{S_X}:{S_X + 1}]")
     cnt.issue_vm("xa")
     out.append(f"global_load_dwordx4 {vr(xb, 4)}, %[xo], s[{S_X}:{S_X + 1}] offset:16")
@@ -191,15 +183,6 @@ def gload_ops(cnt, out, par, xa=None, xb=None, hv=None, off=None):
 def advance_load_pointers(par):
     """SALU: pointers (parity set `par`) of block min(S_K, nhi-1), then S_K += 1."""
     S_X, S_T = SB[par]["x"], SB[par]["t"]
-    if DIRECT:
-        return [
-            f"s_min_u32 s{S_T0}, s{S_K}, s{S_NHI1}",
-            f"s_lshl_b32 s{S_B32}, s{S_T0}, 5",
-            f"s_lshl_b32 s{S_T1}, s{S_T0}, 7",
-            f"s_add_u32 s{S_T}, s{S_TB}, s{S_T1}",
-            f"s_addc_u32 s{S_T + 1}, s{S_TB + 1}, 0",
-            f"s_add_u32 s{S_K}, s{S_K}, 1",
-        ]
     return [
         f"s_min_u32 s{S_T0}, s{S_K}, s{S_NHI1}",
         f"s_lshl_b32 s{S_T1}, s{S_T0}, 8",
@@ -209,21 +192,6 @@ def advance_load_pointers(par):
         f"s_add_u32 s{S_T}, s{S_TB}, s{S_T1}",
         f"s_addc_u32 s{S_T + 1}, s{S_TB + 1}, 0",
         f"s_add_u32 s{S_K}, s{S_K}, 1",
-    ]
-
-
-def offset_ops(par, off=None):
-    """--direct, VALU: offsets and carry mask (parity set `par`) of the sample group
-    s = s0 + S_B32 (advance_load_pointers ran before)."""
-    oi, oc = off if off is not None else OFF[par]
-    mk = MK[par]
-    return [
-        f"v_add_u32 {vr(oc)}, s{S_B32}, %[s0]",
-        f"v_cmp_gt_i32 s[{mk}:{mk + 1}], 0, {vr(oc)}",
-        f"v_max_i32 {vr(oi)}, 0, {vr(oc)}",
-        f"v_min_i32 {vr(oi)}, s{S_SMAX}, {vr(oi)}",
-        f"v_lshlrev_b32 {vr(oi)}, 3, {vr(oi)}",
-        f"v_lshl_add_u32 {vr(oc)}, {vr(oc)}, 3, s{S_CL8}",
     ]
 
 
@@ -288,11 +256,6 @@ def iteration(cnt, out, cur, prev, p_cur, p_prev, label):
                 gaps[g].append(("prod", prod[pi], None))
                 pi += 1
     assert pi == len(prod), (pi, len(prod))
-    if DIRECT:
-        # offsets of the next iteration's loads: after the conversion's wait (gap 10), which
-        # covers the last loads that read this parity's offset registers
-        for i, op in enumerate(offset_ops(other)):
-            gaps[11 + i].append(("addr", op, None))
 
     gaps[17].append(("ldsw", f"ds_write_b128 {vr(V_WR)}, {vr(HI4, 4)}", "wh"))
     gaps[17].append(("ldsw", f"ds_write_b128 {vr(V_WR)}, {vr(LO4, 4)} offset:1024", "wl"))
@@ -354,12 +317,6 @@ def generate():
     o("; ===== prologue =====")
     o(f"s_mov_b32 s{S_XB}, %[xb_lo]")
     o(f"s_mov_b32 s{S_XB + 1}, %[xb_hi]")
-    if DIRECT:
-        o(f"s_mov_b64 s[{S_EXEC}:{S_EXEC + 1}], exec")
-        o(f"s_mov_b32 s{S_CB}, %[cb_lo]")
-        o(f"s_mov_b32 s{S_CB + 1}, %[cb_hi]")
-        o(f"s_mov_b32 s{S_SMAX}, %[smax]")
-        o(f"s_mov_b32 s{S_CL8}, %[cl8]")
     o(f"s_mov_b32 s{S_TB}, %[tp_lo]")
     o(f"s_mov_b32 s{S_TB + 1}, %[tp_hi]")
     o(f"s_mov_b32 s{SB['A']['p']}, %[pp_lo]")
@@ -383,15 +340,13 @@ def generate():
         o(f"s_addc_u32 s{BF[j] + 1}, s{S_BF + 1}, 0")
     o("s_nop 4")
     # (a workgroup that runs the loop for a second row tile keeps them: %[first] == 0)
-    if not DIRECT:
-        o("s_cmp_eq_u32 %[first], 0")
-        o("s_cbranch_scc1 4f")
+    o("s_cmp_eq_u32 %[first], 0")
+    o("s_cbranch_scc1 4f")
     for f in range(16):
         b = BF[f // 4]
         if "bimg" not in ABLATE:
             o(f"global_load_dwordx4 {ar(4 * f)}, %[bo], s[{b}:{b + 1}] offset:{(f % 4) * 1024}")
-    if not DIRECT:
-        o("4:")
+    o("4:")
     # zero: C set B, accumulators, P_B
     for base in (CB[0], CB[1], ACC[0], ACC[1]):
         for i in range(16):
@@ -405,14 +360,8 @@ def generate():
     T2 = (F0 + 12, F0 + 16, F0 + 20)   # of block 2
     OFF_C = (CA[0], CA[0] + 1)          # offsets of block 2: set A is written by the first MFMA only
     out.extend(advance_load_pointers("A"))
-    if DIRECT:
-        out.extend(offset_ops("A"))
     out.extend(advance_load_pointers("B"))
-    if DIRECT:
-        out.extend(offset_ops("B"))
     out.extend(advance_load_pointers("C"))
-    if DIRECT:
-        out.extend(offset_ops("C", OFF_C))
     o("s_nop 4")
     gload_ops(cnt, out, "A")
     gload_ops(cnt, out, "B", *T1)
@@ -430,8 +379,6 @@ def generate():
         o(f"v_mov_b32 {vr(XB + i)}, {vr(T2[1] + i)}")
         o(f"v_mov_b32 {vr(HV + i)}, {vr(T2[2] + i)}")
     out.extend(advance_load_pointers("A"))   # block 3: iteration 0 ("A") loads it
-    if DIRECT:
-        out.extend(offset_ops("A"))
     V_RD, V_RDN, V_WR = ADDR["A"]
     o(f"v_add_u32 {vr(V_RD)}, s{S_RD}, %[lane16]")
     o(f"v_add_u32 {vr(V_RDN)}, s{S_RDN}, %[lane16]")
@@ -443,7 +390,7 @@ def generate():
     o("s_waitcnt lgkmcnt(0)")
     cnt.lgkm = []
     # steady state entry: vm = [hv, xa, xb]; the loop expects [p_prev, hv, xa, xb]
-    XL = ["hv", "xa", "xb", "xa", "xb"] if DIRECT else ["hv", "xa", "xb"]
+    XL = ["hv", "xa", "xb"]
     cnt.vm = ["prB", "pB"] + XL
     o("; ===== main loop, two blocks per trip =====")
     o("1:")
@@ -486,8 +433,8 @@ def generate():
 
 def main():
     lines = generate()
-    PFX = "GSDR_MFMA_RINGD" if DIRECT else "GSDR_MFMA_RING"
-    print("// GENERATED by tools/gen_ddc_mfma_ring.py%s -- do not edit." % (" --direct" if DIRECT else ""))
+    PFX = "GSDR_MFMA_RING"
+    print("// GENERATED by tools/gen_ddc_mfma_ring.py -- do not edit.")
     print("// Main loop of ddc_mfma_ring_kernel: see the generator for the schedule and register map.")
     print("#pragma once")
     print(f"#define {PFX}_VB {VB}")

@@ -15,18 +15,10 @@ contiguous each, no VGPR, no VALU), three blocks ahead of their use in a ring of
 import os
 import sys
 
-DIRECT = False
 # timing-only builds (WRONG results): GEN_ABLATE=rot,prod,lds,gload,bar,bimg drops the rotation
 # FMAs / the conversion arithmetic / the operand reads of the ring / the input loads / the barrier
 # from the loop, the phasor-image loads from the prologue
 ABLATE = set(filter(None, os.environ.get("GEN_ABLATE", "").split(",")))
-# GEN_PRIO: how the two waves that share a SIMD (one of each of the CU's two workgroups) take
-# turns on the matrix pipe.  With equal priorities the OLDER wave wins every arbitration
-# (MI355X_MICROARCH.md, two waves per SIMD, item 2): measured with in-kernel stamps
-# (scratch/stamp_probe.py), the older workgroup of a CU ends after 105 us of a C3 launch, the
-# younger after 145 us, the last 40 us alone on its SIMDs at a third of the pipe rate.
-#   "ab" : priority 1 in the even block of a trip, 0 in the odd one
-PRIO = os.environ.get("GEN_PRIO", "none")
 KS = 4                     # k-steps per block (PK = 32)
 SLOT = KS * 2 * 1024       # bytes of one ring slot
 NSLOT = 4                  # ring slots: images arrive three blocks ahead
@@ -39,13 +31,10 @@ CB = (VB + 64, VB + 80)    # C set B
 F0 = VB + 96               # operand buffers: fragment (k2, rh, sp) at v[F0 + 16*k2 + 8*rh + 4*sp : +3]
 XA, XB, HV = VB + 128, VB + 132, VB + 136
 HI4, LO4 = VB + 140, VB + 144
-HS = VB + 148              # scaled taps of the k-step being converted (4)
 PA = VB + 152              # (Pr, Pi) of tone half 0, (Pr, Pi) of tone half 1: C set A
 PB = VB + 156
-V_SC = VB + 160            # S
 # ring addresses, one set per iteration parity (R2)
 ADDR = {"A": (VB + 161, VB + 162, VB + 163), "B": (VB + 164, VB + 165, VB + 166)}
-OFF = {"A": (0, 0), "B": (0, 0)}
 FALT = VB + 168            # second buffer of the fragments (k-step 0, row half 1): hi 4, lo 4 (even: 64-bit aligned tuples)
 V_LAST = VB + 175
 NVGPR_CLOBBER = list(range(VB, V_LAST + 1))
@@ -64,17 +53,9 @@ S_SC = 48      # s[48:49] = (S, S)
 S_T0, S_T1 = 50, 51
 S_PH = 59      # wave slot parity (HW_ID wave_id & 1): GEN_PRIO=hw
 S_XB = 52      # s[52:53] x base, block 0
-S_TB = 54      # s[54:55] taps base, block 0
 S_BF = 56      # s[56:57] phasor-table images
 S_PSTRIDE = 58
-# --direct
-S_B32 = 59     # 32 * block index of the loads being prepared
-S_SMAX = 72    # L - 4
-S_CL8 = 73     # 8 * carry length
-S_CB = 74      # s[74:75] carry base
-MK = {"A": 80, "B": 82, "C": 84}   # lanes whose group lies in the carry
-S_EXEC = 86    # s[86:87] EXEC on entry
-SGPR_CLOBBER = list(range(36, 88 if DIRECT else 80))
+SGPR_CLOBBER = list(range(36, 80))
 
 
 def vr(base, n=1):
@@ -148,108 +129,6 @@ def rotate_ops(cset, p):
     return ops
 
 
-def produce_ops(xa=None, xb=None, hv=None):
-    """x (4 complex samples in XA, XB) * taps (HV) * S -> fp16 hi (HI4) and lo (LO4): 24 plain
-    VALU instructions (no packed FP32, see tools/gen_ddc_mfma.py).  The product is never formed
-    on its own: hi = f16(x*hs) by v_fma_mixlo/mixhi_f16 (an f32 fma, then one rounding to f16),
-    lo = f16(fma(x, hs, -hi)), the residual of the exact product."""
-    xa, xb, hv = (XA if xa is None else xa), (XB if xb is None else xb), (HV if hv is None else hv)
-    ops = []
-    hs_base = HS
-    if "noscale" in ABLATE:        # timing-only (WRONG results): what pre-scaled taps would save
-        hs_base = hv
-    else:
-        for j in range(4):
-            ops.append(f"v_mul_f32 {vr(HS + j)}, {vr(hv + j)}, {vr(V_SC)}")
-    xs = [xa, xa + 2, xb, xb + 2]
-    if os.environ.get("GEN_CONV", "mul") == "mul":     # default; GEN_CONV=mix: 24 instructions through v_fma_mixlo/hi_f16, measured 1.2 % SLOWER on C3 (same box, scratch/ab.sh)
-        for j in range(4):
-            ops.append(f"v_mul_f32 {vr(xs[j])}, {vr(xs[j])}, {vr(hs_base + j)}")
-            ops.append(f"v_mul_f32 {vr(xs[j] + 1)}, {vr(xs[j] + 1)}, {vr(hs_base + j)}")
-        for j in range(4):
-            ops.append(f"v_cvt_pk_f16_f32 {vr(HI4 + j)}, {vr(xs[j])}, {vr(xs[j] + 1)}")
-        for j in range(4):
-            ops.append(f"v_fma_mix_f32 {vr(xs[j])}, {vr(xs[j])}, 1.0, -{vr(HI4 + j)} op_sel_hi:[0,0,1]")
-            ops.append(f"v_fma_mix_f32 {vr(xs[j] + 1)}, {vr(xs[j] + 1)}, 1.0, -{vr(HI4 + j)} op_sel:[0,0,1] op_sel_hi:[0,0,1]")
-        for j in range(4):
-            ops.append(f"v_cvt_pk_f16_f32 {vr(LO4 + j)}, {vr(xs[j])}, {vr(xs[j] + 1)}")
-        return ops
-    for j in range(4):
-        ops.append(f"v_fma_mixlo_f16 {vr(HI4 + j)}, {vr(xs[j])}, {vr(HS + j)}, 0")
-        ops.append(f"v_fma_mixhi_f16 {vr(HI4 + j)}, {vr(xs[j] + 1)}, {vr(HS + j)}, 0")
-    for j in range(4):
-        ops.append(f"v_fma_mix_f32 {vr(xs[j])}, {vr(xs[j])}, {vr(HS + j)}, -{vr(HI4 + j)} op_sel_hi:[0,0,1]")
-        ops.append(f"v_fma_mix_f32 {vr(xs[j] + 1)}, {vr(xs[j] + 1)}, {vr(HS + j)}, -{vr(HI4 + j)} op_sel:[0,0,1] op_sel_hi:[0,0,1]")
-    for j in range(4):
-        ops.append(f"v_cvt_pk_f16_f32 {vr(LO4 + j)}, {vr(xs[j])}, {vr(xs[j] + 1)}")
-    return ops
-
-
-def gload_ops(cnt, out, par, xa=None, xb=None, hv=None, off=None):
-    S_X, S_T = SB[par]["x"], SB[par]["t"]
-    xa, xb, hv = (XA if xa is None else xa), (XB if xb is None else xb), (HV if hv is None else hv)
-    out.append(f"global_load_dwordx4 {vr(hv, 4)}, %[to], s[{S_T}:{S_T + 1}]")
-    cnt.issue_vm("hv")
-    if DIRECT:
-        oi, oc = off if off is not None else OFF[par]
-        mk = MK[par]
-        out.append(f"s_andn2_b64 exec, exec, s[{mk}:{mk + 1}]")
-        out.append(f"global_load_dwordx4 {vr(xa, 4)}, {vr(oi)}, s[{S_XB}:{S_XB + 1}]")
-        cnt.issue_vm("xa")
-        out.append(f"global_load_dwordx4 {vr(xb, 4)}, {vr(oi)}, s[{S_XB}:{S_XB + 1}] offset:16")
-        cnt.issue_vm("xb")
-        out.append(f"s_and_b64 exec, s[{S_EXEC}:{S_EXEC + 1}], s[{mk}:{mk + 1}]")
-        out.append(f"global_load_dwordx4 {vr(xa, 4)}, {vr(oc)}, s[{S_CB}:{S_CB + 1}]")
-        cnt.issue_vm("xa")
-        out.append(f"global_load_dwordx4 {vr(xb, 4)}, {vr(oc)}, s[{S_CB}:{S_CB + 1}] offset:16")
-        cnt.issue_vm("xb")
-        out.append(f"s_mov_b64 exec, s[{S_EXEC}:{S_EXEC + 1}]")
-        return
-    out.append(f"global_load_dwordx4 {vr(xa, 4)}, %[xo], s[{S_X}:{S_X + 1}]")
-    cnt.issue_vm("xa")
-    out.append(f"global_load_dwordx4 {vr(xb, 4)}, %[xo], s[{S_X}:{S_X + 1}] offset:16")
-    cnt.issue_vm("xb")
-
-
-def advance_load_pointers(par):
-    """SALU: pointers (parity set `par`) of block min(S_K, nhi-1), then S_K += 1."""
-    S_X, S_T = SB[par]["x"], SB[par]["t"]
-    if DIRECT:
-        return [
-            f"s_min_u32 s{S_T0}, s{S_K}, s{S_NHI1}",
-            f"s_lshl_b32 s{S_B32}, s{S_T0}, 5",
-            f"s_lshl_b32 s{S_T1}, s{S_T0}, 7",
-            f"s_add_u32 s{S_T}, s{S_TB}, s{S_T1}",
-            f"s_addc_u32 s{S_T + 1}, s{S_TB + 1}, 0",
-            f"s_add_u32 s{S_K}, s{S_K}, 1",
-        ]
-    return [
-        f"s_min_u32 s{S_T0}, s{S_K}, s{S_NHI1}",
-        f"s_lshl_b32 s{S_T1}, s{S_T0}, 8",
-        f"s_add_u32 s{S_X}, s{S_XB}, s{S_T1}",
-        f"s_addc_u32 s{S_X + 1}, s{S_XB + 1}, 0",
-        f"s_lshl_b32 s{S_T1}, s{S_T0}, 7",
-        f"s_add_u32 s{S_T}, s{S_TB}, s{S_T1}",
-        f"s_addc_u32 s{S_T + 1}, s{S_TB + 1}, 0",
-        f"s_add_u32 s{S_K}, s{S_K}, 1",
-    ]
-
-
-def offset_ops(par, off=None):
-    """--direct, VALU: offsets and carry mask (parity set `par`) of the sample group
-    s = s0 + S_B32 (advance_load_pointers ran before)."""
-    oi, oc = off if off is not None else OFF[par]
-    mk = MK[par]
-    return [
-        f"v_add_u32 {vr(oc)}, s{S_B32}, %[s0]",
-        f"v_cmp_gt_i32 s[{mk}:{mk + 1}], 0, {vr(oc)}",
-        f"v_max_i32 {vr(oi)}, 0, {vr(oc)}",
-        f"v_min_i32 {vr(oi)}, s{S_SMAX}, {vr(oi)}",
-        f"v_lshlrev_b32 {vr(oi)}, 3, {vr(oi)}",
-        f"v_lshl_add_u32 {vr(oc)}, {vr(oc)}, 3, s{S_CL8}",
-    ]
-
-
 # MFMA order inside k-step k2: (row half, hi|lo of the A fragment) major.  Entries:
 # (rh, sp_a, th, c, sp_b); the first 8 of a row half use its hi fragment (products hi*hi, hi*lo),
 # the next 4 its lo fragment (lo*hi).
@@ -268,16 +147,6 @@ def kstep_order():
 
 ORDER = kstep_order()
 assert len(ORDER) == 24
-
-
-def mfma(cset, g):
-    cr, ci = cset
-    k2, m = divmod(g, 24)
-    rh, sp_a, th, c, sp_b = ORDER[m]
-    dst = (cr if c == 0 else ci) + 4 * (2 * rh + th)
-    first = k2 == 0 and sp_a == 0 and sp_b == 0
-    src_c = "0" if first else vr(dst, 4)
-    return f"v_mfma_f32_16x16x32_f16 {vr(dst, 4)}, {vr(frag(k2, rh, sp_a), 4)}, {bfrag(k2, th, c, sp_b)}, {src_c}"
 
 
 def first_use(k2, rh, sp):

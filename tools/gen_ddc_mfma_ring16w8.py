@@ -22,7 +22,6 @@ the same on both paths.
 import os
 import sys
 
-DIRECT = False
 # timing-only builds (WRONG results): GEN_ABLATE=rot,prod,lds,gload,bar,bimg drops the rotation
 # FMAs / the conversion arithmetic / the operand reads of the ring / the input loads / the barrier
 # from the loop, the phasor-image loads from the prologue
@@ -51,7 +50,6 @@ PB = VB + 156
 V_SC = VB + 160            # S
 # ring addresses, one set per iteration parity (R2)
 ADDR = {"A": (VB + 161, VB + 162, VB + 163), "B": (VB + 164, VB + 165, VB + 166)}
-OFF = {"A": (0, 0), "B": (0, 0)}
 FALT = VB + 168            # second buffer of the fragments (k-step 0, row half 1): hi 4, lo 4 (even: 64-bit aligned tuples)
 V_LAST = VB + 175
 NVGPR_CLOBBER = list(range(VB, V_LAST + 1))
@@ -70,14 +68,7 @@ S_XB = 52      # s[52:53] x base, block 0
 S_TB = 54      # s[54:55] taps base, block 0
 S_BF = 56      # s[56:57] phasor-table images
 S_PSTRIDE = 58
-# --direct
-S_B32 = 59     # 32 * block index of the loads being prepared
-S_SMAX = 72    # L - 4
-S_CL8 = 73     # 8 * carry length
-S_CB = 74      # s[74:75] carry base
-MK = {"A": 80, "B": 82, "C": 84}   # lanes whose group lies in the carry
-S_EXEC = 86    # s[86:87] EXEC on entry
-SGPR_CLOBBER = list(range(36, 88 if DIRECT else 80))
+SGPR_CLOBBER = list(range(36, 80))
 
 
 def vr(base, n=1):
@@ -153,7 +144,7 @@ def rotate_ops(cset, p):
 
 def produce_ops(xa=None, xb=None, hv=None):
     """x (4 complex samples in XA, XB) * taps (HV) * S -> fp16 hi (HI4) and lo (LO4): 24 plain
-    VALU instructions (no packed FP32, see tools/gen_ddc_mfma.py).  The product is never formed
+    VALU instructions (no packed FP32, see tools/gen_ddc_mfma_ring.py).  The product is never formed
     on its own: hi = f16(x*hs) by v_fma_mixlo/mixhi_f16 (an f32 fma, then one rounding to f16),
     lo = f16(fma(x, hs, -hi)), the residual of the exact product."""
     xa, xb, hv = (XA if xa is None else xa), (XB if xb is None else xb), (HV if hv is None else hv)
@@ -189,21 +180,6 @@ def gload_ops(cnt, out, par, xa=None, xb=None, hv=None, off=None):
     xa, xb, hv = (XA if xa is None else xa), (XB if xb is None else xb), (HV if hv is None else hv)
     out.append(f"global_load_dwordx4 {vr(hv, 4)}, %[to], s[{S_T}:{S_T + 1}]")
     cnt.issue_vm("hv")
-    if DIRECT:
-        oi, oc = off if off is not None else OFF[par]
-        mk = MK[par]
-        out.append(f"s_andn2_b64 exec, exec, s[{mk}:{mk + 1}]")
-        out.append(f"global_load_dwordx4 {vr(xa, 4)}, {vr(oi)}, s[{S_XB}:{S_XB + 1}]")
-        cnt.issue_vm("xa")
-        out.append(f"global_load_dwordx4 {vr(xb, 4)}, {vr(oi)}, s[{S_XB}:{S_XB + 1}] offset:16")
-        cnt.issue_vm("xb")
-        out.append(f"s_and_b64 exec, s[{S_EXEC}:{S_EXEC + 1}], s[{mk}:{mk + 1}]")
-        out.append(f"global_load_dwordx4 {vr(xa, 4)}, {vr(oc)}, s[{S_CB}:{S_CB + 1}]")
-        cnt.issue_vm("xa")
-        out.append(f"global_load_dwordx4 {vr(xb, 4)}, {vr(oc)}, s[{S_CB}:{S_CB + 1}] offset:16")
-        cnt.issue_vm("xb")
-        out.append(f"s_mov_b64 exec, s[{S_EXEC}:{S_EXEC + 1}]")
-        return
     out.append(f"global_load_dwordx4 {vr(xa, 4)}, %[xo], s[{S_X}:{S_X + 1}]")
     cnt.issue_vm("xa")
     out.append(f"global_load_dwordx4 {vr(xb, 4)}, %[xo], s[{S_X}:{S_X + 1}] offset:16")
@@ -213,15 +189,6 @@ def gload_ops(cnt, out, par, xa=None, xb=None, hv=None, off=None):
 def advance_load_pointers(par):
     """SALU: pointers (parity set `par`) of block min(S_K, nhi-1), then S_K += 1."""
     S_X, S_T = SB[par]["x"], SB[par]["t"]
-    if DIRECT:
-        return [
-            f"s_min_u32 s{S_T0}, s{S_K}, s{S_NHI1}",
-            f"s_lshl_b32 s{S_B32}, s{S_T0}, 5",
-            f"s_lshl_b32 s{S_T1}, s{S_T0}, 7",
-            f"s_add_u32 s{S_T}, s{S_TB}, s{S_T1}",
-            f"s_addc_u32 s{S_T + 1}, s{S_TB + 1}, 0",
-            f"s_add_u32 s{S_K}, s{S_K}, 1",
-        ]
     return [
         f"s_min_u32 s{S_T0}, s{S_K}, s{S_NHI1}",
         f"s_lshl_b32 s{S_T1}, s{S_T0}, 8",
@@ -231,21 +198,6 @@ def advance_load_pointers(par):
         f"s_add_u32 s{S_T}, s{S_TB}, s{S_T1}",
         f"s_addc_u32 s{S_T + 1}, s{S_TB + 1}, 0",
         f"s_add_u32 s{S_K}, s{S_K}, 2",
-    ]
-
-
-def offset_ops(par, off=None):
-    """--direct, VALU: offsets and carry mask (parity set `par`) of the sample group
-    s = s0 + S_B32 (advance_load_pointers ran before)."""
-    oi, oc = off if off is not None else OFF[par]
-    mk = MK[par]
-    return [
-        f"v_add_u32 {vr(oc)}, s{S_B32}, %[s0]",
-        f"v_cmp_gt_i32 s[{mk}:{mk + 1}], 0, {vr(oc)}",
-        f"v_max_i32 {vr(oi)}, 0, {vr(oc)}",
-        f"v_min_i32 {vr(oi)}, s{S_SMAX}, {vr(oi)}",
-        f"v_lshlrev_b32 {vr(oi)}, 3, {vr(oi)}",
-        f"v_lshl_add_u32 {vr(oc)}, {vr(oc)}, 3, s{S_CL8}",
     ]
 
 
@@ -267,16 +219,6 @@ def kstep_order():
 
 ORDER = kstep_order()
 assert len(ORDER) == 24
-
-
-def mfma(cset, g):
-    cr, ci = cset
-    k2, m = divmod(g, 24)
-    rh, sp_a, th, c, sp_b = ORDER[m]
-    dst = (cr if c == 0 else ci) + 4 * (2 * rh + th)
-    first = k2 == 0 and sp_a == 0 and sp_b == 0
-    src_c = "0" if first else vr(dst, 4)
-    return f"v_mfma_f32_16x16x32_f16 {vr(dst, 4)}, {vr(frag(k2, rh, sp_a), 4)}, {bfrag(k2, th, c, sp_b)}, {src_c}"
 
 
 def first_use(k2, rh, sp):
