@@ -489,7 +489,7 @@ def kernel_seconds(r):
     return (r["kernel_ms"] / r["kernel_launches"] * 1e-3) if r["kernel_launches"] else None
 
 
-def rooflines(wl, r, key):
+def rooflines(wl, r, key, period_s=None):
     """(roofline of the bounding pipe, HBM roofline) of the dominant kernel from the hipEvent
     durations `r` (a time_workload() result) carries; (None, None) without them.
 
@@ -498,11 +498,19 @@ def rooflines(wl, r, key):
     kt = kernel_seconds(r)
     if not kt:
         return None, None
+    how = f"hipEvents on the launch stream, {r['api']} entry"
+    extra = {}
+    if period_s is not None and period_s < kt:
+        extra = dict(kernel_us_between_events=round(kt * 1e6, 2))
+        how = (f"step period of back-to-back launches on one stream (one kernel per step, {r['api']} entry, no events in "
+               "the region): an upper bound of the launch duration; a hipEvent pair around a launch this short adds "
+               "~2.5 us (kernel_us_between_events); rocprofv3 --kernel-trace: profiles/")
+        kt = period_s
     gbs = ab * L / kt / 1e9
     tfl = af * L / kt / 1e12
     traffic = recorded_traffic(key)
     common = dict(traffic=traffic, kernel=r["kernel"], kernel_us=round(kt * 1e6, 2), launches_timed=r["kernel_launches"],
-                  measured_with=f"hipEvents on the launch stream, {r['api']} entry")
+                  measured_with=how, **extra)
     roof_hbm = dict(bound="hbm", achieved=round(gbs, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(gbs / HBM_PEAK_GBS, 5), algorithmic_bytes_per_launch=round(ab * L), **common)
     if wl["kind"] in ("direct", "pfb") and r["kernel"].startswith("ddc_mfma"):
@@ -537,11 +545,17 @@ def measure(engine, key, device, seed, steps, warmup, dist, api, min_seconds, wi
     in-order pass the roofline is taken from: a launch of the overlapped entry shares the chip
     with its neighbours, so its duration is not the kernel's."""
     wl = WORKLOADS[key]
-    r = time_workload(engine, wl, device, seed, steps, warmup, dist, api=api, min_seconds=min_seconds)
+    # chirp: a step is ONE launch of ~4 us; an event pair around it costs ~2.5 us of stream time, so the
+    # timed region of `value` carries no events and the event-bracketed durations come from a pass of their own
+    short_step = wl["kind"] == "chirp"
+    r = time_workload(engine, wl, device, seed, steps, warmup, dist, api=api, min_seconds=min_seconds,
+                      profile_every=0 if short_step else None)
     world = dist.get_world_size() if dist is not None else 1
     res = dict(r=r, value=r["total_steps"] * L * world / r["elapsed"] / 1e6,
                ms_per_step=r["elapsed"] / r["total_steps"] * 1e3)
     ri = r
+    if short_step:
+        ri = time_workload(engine, wl, device, seed, steps, warmup, dist, api=api, min_seconds=min(min_seconds, 0.3))
     if api == "pipelined" and with_inorder:
         ri = time_workload(engine, wl, device, seed, steps, warmup, dist, api="inorder",
                            min_seconds=min_seconds, profile_every=4)
@@ -549,8 +563,10 @@ def measure(engine, key, device, seed, steps, warmup, dist, api, min_seconds, wi
                               value=round(ri["total_steps"] * L / ri["local_elapsed"] / 1e6, 2),
                               unit="Msamples/s per GPU", repeats=ri["repeats"],
                               ms_per_step=round(ri["local_elapsed"] / ri["total_steps"] * 1e3, 5))
-    roof, roof_hbm = rooflines(wl, ri, key)
-    if roof and ri is not r:
+    # one kernel per step, steps back to back on one stream: the step period of the event-free region
+    # bounds the launch duration from above
+    roof, roof_hbm = rooflines(wl, ri, key, period_s=r["local_elapsed"] / r["total_steps"] if short_step else None)
+    if roof and ri is not r and not short_step:
         kt = kernel_seconds(r)
         if kt:
             for ro in {id(roof): roof, id(roof_hbm): roof_hbm}.values():
@@ -559,7 +575,7 @@ def measure(engine, key, device, seed, steps, warmup, dist, api, min_seconds, wi
                     launches_in_flight=round(kt / (r["local_elapsed"] / r["total_steps"]), 2),
                     note="average launch duration inside the timed region of `value`, where up to "
                          f"{PIPE_DEPTH} launches share the chip")
-    if roof and ri is not r and ri["kernel"] != r["kernel"]:
+    if roof and ri is not r and not short_step and ri["kernel"] != r["kernel"]:
         roof["note"] = (f"kernel / kernel_us are those of the in-order pass ({ri['kernel']}: the library picks the kernel per "
                         f"launch, DESIGN.md 4.1a/4.1b); the overlapped entry that `value` is timed through ran {r['kernel']} "
                         f"(+ ddc_convert_kernel when that is the pre-converted path); same tables, bit-identical results")

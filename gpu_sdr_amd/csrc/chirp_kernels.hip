@@ -35,12 +35,12 @@ __device__ __forceinline__ void sincos_index(int index, float &s, float &c) {
     cp = fmaf(a2, cp, 4.1666666666666664e-02f);
     cp = fmaf(a2, cp, -0.5f);
     const float cn = fmaf(a2, cp, 1.0f);
-    switch (quad & 3u) {
-        case 0: s = sn;  c = cn;  break;
-        case 1: s = cn;  c = -sn; break;
-        case 2: s = -sn; c = -cn; break;
-        default: s = -cn; c = sn; break;
-    }
+    // quarter-turn rotation without branches (a switch here compiles to four divergent
+    // branches per sample): quad 0: (sn, cn), 1: (cn, -sn), 2: (-sn, -cn), 3: (-cn, sn)
+    const bool swap = (quad & 1u) != 0;
+    const unsigned s_sign = (quad & 2u) << 30, c_sign = ((quad + 1u) & 2u) << 30;
+    s = __uint_as_float(__float_as_uint(swap ? cn : sn) ^ s_sign);
+    c = __uint_as_float(__float_as_uint(swap ? sn : cn) ^ c_sign);
 }
 
 // ref: kernels.cu:407-419.  The reference evaluates this in 64-bit unsigned
@@ -77,6 +77,24 @@ __device__ __forceinline__ float2 demod_one(float2 in, int index) {
     o.x = chx * in.x + chy * in.y;
     o.y = chx * in.y - chy * in.x;
     return o;
+}
+
+// Sum over the 64 lanes of a wave with DPP row operations (a butterfly of __shfl_xor is six
+// dependent ds_bpermute round trips through the LDS crossbar, ~0.7 us at the end of a wave that
+// lives 3 us); the total arrives in lane 63.
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+    int x = __float_as_int(v);
+#define GSDR_DPP_ADD(ctrl, row_mask)                                                                    \
+    x = __float_as_int(__int_as_float(x) +                                                              \
+                       __int_as_float(__builtin_amdgcn_update_dpp(0, x, ctrl, row_mask, 0xf, false)))
+    GSDR_DPP_ADD(0xB1, 0xf);    // quad_perm [1,0,3,2]
+    GSDR_DPP_ADD(0x4E, 0xf);    // quad_perm [2,3,0,1]
+    GSDR_DPP_ADD(0x141, 0xf);   // row_half_mirror
+    GSDR_DPP_ADD(0x140, 0xf);   // row_mirror: every lane holds the sum of its row of 16
+    GSDR_DPP_ADD(0x142, 0xa);   // row_bcast:15 into rows 1 and 3
+    GSDR_DPP_ADD(0x143, 0xc);   // row_bcast:31 into rows 2 and 3
+#undef GSDR_DPP_ADD
+    return __int_as_float(x);
 }
 
 __global__ __launch_bounds__(256) void chirp_demod_generic_kernel(const float2 *__restrict__ in,
@@ -155,11 +173,34 @@ __device__ __forceinline__ unsigned wrap_index(unsigned long long index0, unsign
     return (unsigned)(t >= per ? t - per : t);
 }
 
-// One wave per output point.  All loads of a 256-sample stretch are issued before
-// any of them is used (one memory round trip per stretch, not one per sample).
+// One wave per output point.  The samples are taken in stretches of 256 (4 per lane); the loads
+// of a stretch are issued one stretch ahead -- those of the first one in front of the index
+// arithmetic of the prologue (three integer divisions), which then runs in their shadow -- and
+// carry no branch (clamped addresses, the weight of a lane beyond the step is zeroed by a select).
+// With ppt = 200 (C4) a wave lives for one memory round trip: the launch is 5000 such waves.
+struct ChirpStretch {
+    float2 smp[4];
+    float w[4];
+};
+
+__device__ __forceinline__ void load_stretch(ChirpStretch &c, const float2 *__restrict__ carry, int carry_len,
+                                             const float2 *__restrict__ in, const float *__restrict__ w_seg,
+                                             unsigned seg, unsigned r0, unsigned len, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned r = r0 + (unsigned)(i * 64 + lane);
+        const bool ok = r < len;
+        const unsigned rc = ok ? r : 0u;
+        const unsigned pos = seg + rc;
+        const float2 *p = (int)pos < carry_len ? carry + pos : in + (pos - (unsigned)carry_len);
+        c.smp[i] = *p;
+        c.w[i] = w_seg[rc];          // zeroed at the use (a select here would wait for the load)
+    }
+}
+
 __global__ __launch_bounds__(256) void chirp_lockin_kernel(
     const float2 *__restrict__ carry, int carry_len, const float2 *__restrict__ in,
-    const float *__restrict__ profile, int ppt, int valid, float2 *__restrict__ out,
+    const float *__restrict__ profile, int ppt, int decim, int valid, float2 *__restrict__ out,
     unsigned long long index0, ChirpShape cs) {
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -167,42 +208,49 @@ __global__ __launch_bounds__(256) void chirp_lockin_kernel(
     if (v >= valid) return;
     const unsigned len = (unsigned)cs.length, steps = (unsigned)cs.num_steps;
     const unsigned base = (unsigned)v * (unsigned)ppt;  // position in the logical stage [carry | in]
+    ChirpStretch cur, nxt;
+    load_stretch(cur, carry, carry_len, in, profile, base, 0u, len, lane);
+    asm volatile("" ::: "memory");                      // the loads stay in front of the divisions
     const unsigned e0 = wrap_index(index0, base, cs);   // a multiple of len
     unsigned fi = e0 / len;
-    const int decim = ppt / (int)len;
     float sx = 0.f, sy = 0.f;
-    for (int d = 0; d < decim; ++d) {
+    for (int d = 0; d < decim; ++d) {         // decim = ppt / len steps per point
         unsigned A, K;
         step_coeffs(fi, cs, A, K);
-        const unsigned seg = base + (unsigned)d * len;
-        const float *w_seg = profile + (size_t)d * len;
+        float sd, cd;
+        sincos_index((int)(64u * A), sd, cd);
         for (unsigned r0 = 0; r0 < len; r0 += 256) {
-            float w[4];
-            float2 smp[4];
+            // the stretch after this one: same step, or the head of the next step
+            const bool more_here = r0 + 256 < len;
+            if (more_here || d + 1 < decim) {
+                const unsigned nd = more_here ? (unsigned)d : (unsigned)d + 1u;
+                load_stretch(nxt, carry, carry_len, in, profile + (size_t)nd * len, base + nd * len,
+                             more_here ? r0 + 256 : 0u, len, lane);
+            }
+            // the lane's four samples are 64 apart: inside a step the index advances by 64*A (mod 2^32),
+            // the chirp phasor by one fixed rotation -- one sincos per lane and stretch instead of four
+            float sn, cn;
+            sincos_index((int)(K + (r0 + (unsigned)lane) * A), sn, cn);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const unsigned r = r0 + (unsigned)(i * 64 + lane);
-                const bool ok = r < len;
-                const unsigned pos = seg + (ok ? r : 0u);
-                w[i] = ok ? w_seg[r] : 0.f;
-                smp[i] = (int)pos < carry_len ? carry[pos] : in[pos - (unsigned)carry_len];
+                const float2 in = cur.smp[i];
+                const float chx = sn, chy = -cn;     // chirp = (sinpi, -cospi); in * conj(chirp): demod_one()
+                const float dx = chx * in.x + chy * in.y, dy = chx * in.y - chy * in.x;
+                const float w = r < len ? cur.w[i] : 0.f;
+                sx = fmaf(dx, w, sx);
+                sy = fmaf(dy, w, sy);
+                const float s2 = fmaf(sn, cd, cn * sd), c2 = fmaf(cn, cd, -(sn * sd));
+                sn = s2;
+                cn = c2;
             }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const unsigned r = r0 + (unsigned)(i * 64 + lane);
-                const float2 dm = demod_one(smp[i], (int)(K + r * A));
-                sx = fmaf(dm.x, w[i], sx);
-                sy = fmaf(dm.y, w[i], sy);
-            }
+            cur = nxt;
         }
         fi = fi + 1 == steps ? 0 : fi + 1;
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        sx += __shfl_xor(sx, off, 64);
-        sy += __shfl_xor(sy, off, 64);
-    }
-    if (lane == 0) out[v] = make_float2(sx, sy);
+    sx = wave_sum_to_lane63(sx);
+    sy = wave_sum_to_lane63(sy);
+    if (lane == 63) out[v] = make_float2(sx, sy);
 }
 
 // Undecimated demodulation: 4 consecutive runs of 64 samples per wave; the step
@@ -263,7 +311,7 @@ hipError_t launch_chirp_lockin(const float2 *carry, int carry_len, const float2 
     // true for every window the demodulator forms (ppt = length*decim, see enqueue_chirp)
     if (chirp_fits_32(cs) && ppt % (int)cs.length == 0 && index0 % cs.length == 0)
         hipLaunchKernelGGL(chirp_lockin_kernel, dim3((unsigned)((valid + 3) / 4)), dim3(256), 0, st,
-                           carry, carry_len, in, profile, ppt, valid, out, index0, cs);
+                           carry, carry_len, in, profile, ppt, ppt / (int)cs.length, valid, out, index0, cs);
     else
         hipLaunchKernelGGL(chirp_lockin_generic_kernel, dim3((unsigned)((valid + 3) / 4)), dim3(256),
                            0, st, carry, carry_len, in, profile, ppt, valid, out, index0, cs);

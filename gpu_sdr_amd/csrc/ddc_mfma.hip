@@ -135,7 +135,7 @@ __device__ __forceinline__ void stamp(int slot) {
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
             t = (xcc & 0xfu) | ((unsigned long long)hwid << 8);
         }
-        g_stamp_buf[4 * (size_t)blockIdx.x + slot] = t;
+        g_stamp_buf[8 * (size_t)blockIdx.x + slot] = t;
     }
 }
 #else
@@ -169,16 +169,25 @@ __device__ __forceinline__ float2 tile_phasor(const MfmaLaunch &a, int gt, unsig
 }
 
 // rot[n,o] = w_n^(idx_base + o*M) / S applied to the accumulators, then the stores.
-__device__ __forceinline__ void store_tile(const MfmaLaunch &a, int gt, int n, int hh, float invS, float2 base,
+// Every table load is issued before the first one is waited for: with the loads inside the range
+// guard of the stores the compiler emits sixteen load -> wait -> store round trips, one after the
+// other (4.5 us of a 20 us workgroup on C2, scratch/stamp_c2_phases.sh).  The tables are padded to
+// whole tiles, so the loads need no guard.
+__device__ __forceinline__ void store_tile(const MfmaLaunch &a, int gt, int n, int hh, float invS,
                                            const float16v &accr, const float16v &acci) {
     const MfmaShape &sh = a.sh;
     const int Np = sh.NT32 * 32;
+    const unsigned fm = a.fmod[n];
+    float2 d[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) d[i] = a.dtab[(size_t)((i & 3) + 8 * (i >> 2) + 4 * hh) * Np + n];
+    asm volatile("" ::: "memory");          // the loads stay above the phasor arithmetic
+    const float2 base = tile_phasor(a, gt, fm);
     const float br = base.x * invS, bi = base.y * invS;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
-        const float2 d = a.dtab[(size_t)row * Np + n];
-        const float rr = br * d.x - bi * d.y, ri = br * d.y + bi * d.x;
+        const float rr = br * d[i].x - bi * d[i].y, ri = br * d[i].y + bi * d[i].x;
         float2 y;
         y.x = accr[i] * rr - acci[i] * ri;
         y.y = accr[i] * ri + acci[i] * rr;
@@ -193,7 +202,7 @@ __device__ __forceinline__ void store_rows(const MfmaLaunch &a, int gt, int n0, 
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) {
         const int n = n0 + tt * 32;
-        store_tile(a, gt, n, hh, invS, tile_phasor(a, gt, a.fmod[n]), accr[tt], acci[tt]);
+        store_tile(a, gt, n, hh, invS, accr[tt], acci[tt]);
     }
 }
 
@@ -441,7 +450,7 @@ __device__ __forceinline__ __attribute__((target("no-packed-fp32-ops"))) void ri
             }
         }
         const int n = tg * 32 + (lane2 & 31);
-        store_tile(a, gt, n, lane2 >> 5, invS, tile_phasor(a, gt, a.fmod[n]), accr, acci);
+        store_tile(a, gt, n, lane2 >> 5, invS, accr, acci);
     }
 }
 
@@ -489,15 +498,25 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
 //                                                   tone 16*th + (l & 15) of the wave's 32.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ __attribute__((target("no-packed-fp32-ops"))) void store_tile16(
-    const MfmaLaunch &a, int gt, int tg, int lane, float invS, float2 base_self, const float16v &accr,
-    const float16v &acci) {
+    const MfmaLaunch &a, int gt, int tg, int lane, float invS, const float16v &accr, const float16v &acci) {
     const MfmaShape &sh = a.sh;
     const int Np = sh.NT32 * 32;
     const int l15 = lane & 15, l4 = lane >> 4;
+    // all table loads first (see store_tile); every lane computes the tile phasor of tone lane & 31
+    const unsigned fm = a.fmod[tg * 32 + (lane & 31)];
+    float2 d[16];
+#pragma unroll
+    for (int th = 0; th < 2; ++th)
+#pragma unroll
+        for (int rh = 0; rh < 2; ++rh)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                d[4 * (2 * rh + th) + j] = a.dtab[(size_t)(16 * rh + 4 * l4 + j) * Np + tg * 32 + 16 * th + l15];
+    asm volatile("" ::: "memory");
+    const float2 base_self = tile_phasor(a, gt, fm);
 #pragma unroll
     for (int th = 0; th < 2; ++th) {
-        // lane 16*th + l15 holds the tile phasor of tone 16*th + l15 (every lane computed the one
-        // of tone lane & 31)
+        // lane 16*th + l15 holds the tile phasor of tone 16*th + l15
         const int src = (16 * th + l15) << 2;
         const float bx = bits_to_float((unsigned)__builtin_amdgcn_ds_bpermute(src, (int)float_to_bits(base_self.x)));
         const float by = bits_to_float((unsigned)__builtin_amdgcn_ds_bpermute(src, (int)float_to_bits(base_self.y)));
@@ -509,8 +528,7 @@ __device__ __forceinline__ __attribute__((target("no-packed-fp32-ops"))) void st
             for (int j = 0; j < 4; ++j) {
                 const int i = 4 * (2 * rh + th) + j;
                 const int row = 16 * rh + 4 * l4 + j;
-                const float2 d = a.dtab[(size_t)row * Np + n];
-                const float rr = br * d.x - bi * d.y, ri = br * d.y + bi * d.x;
+                const float rr = br * d[i].x - bi * d[i].y, ri = br * d[i].y + bi * d[i].x;
                 float2 y;
                 y.x = accr[i] * rr - acci[i] * ri;
                 y.y = accr[i] * ri + acci[i] * rr;
@@ -560,6 +578,7 @@ __device__ __forceinline__ __attribute__((target("no-packed-fp32-ops"))) void ri
     }
     const unsigned xo = (unsigned)((((long long)(oc + sh.woff) * sh.M + xshift) + 4 * hh + 8 * wave) * 8);
     const unsigned long long xb = (unsigned long long)xbase;
+    stamp(4);
     asm volatile(GSDR_MFMA_RING16_TEXT
                  :
                  : [xo] "v"(xo), [to] "v"(to), [po] "v"(po), [bo] "v"(bo), [lane16] "v"(rd16), [wr16] "v"(wr16),
@@ -576,6 +595,7 @@ __device__ __forceinline__ __attribute__((target("no-packed-fp32-ops"))) void ri
                    [first] "s"(__builtin_amdgcn_readfirstlane(first)),
                    [scale] "v"(S)
                  : GSDR_MFMA_RING16_CLOBBERS);
+    stamp(3);
     if (active && !timing_no_stores(sh)) {
         unsigned tid2 = threadIdx.x;
         asm volatile("" : "+v"(tid2));
@@ -592,8 +612,7 @@ __device__ __forceinline__ __attribute__((target("no-packed-fp32-ops"))) void ri
                 acci[qd * 4 + j] = vi[j];
             }
         }
-        const int n_self = tg * 32 + (lane2 & 31);
-        store_tile16(a, gt, tg, lane2, invS, tile_phasor(a, gt, a.fmod[n_self]), accr, acci);
+        store_tile16(a, gt, tg, lane2, invS, accr, acci);
     }
 }
 
@@ -725,8 +744,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((target("no-packed-fp32-ops")
                 acci[qd * 4 + j] = vi[j];
             }
         }
-        const int n_self = tg * 32 + (lane2 & 31);
-        store_tile16(a, gt, tg, lane2, invS, tile_phasor(a, gt, a.fmod[n_self]), accr, acci);
+        store_tile16(a, gt, tg, lane2, invS, accr, acci);
     }
     stamp(1);
 }
@@ -812,8 +830,7 @@ __device__ __forceinline__ __attribute__((target("no-packed-fp32-ops"))) void ri
                 acci[qd * 4 + j] = vi[j];
             }
         }
-        const int n_self = tg * 32 + (lane2 & 31);
-        store_tile16(a, gt, tg, lane2, invS, tile_phasor(a, gt, a.fmod[n_self]), accr, acci);
+        store_tile16(a, gt, tg, lane2, invS, accr, acci);
     }
 }
 

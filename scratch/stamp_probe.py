@@ -13,7 +13,7 @@ wl = bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "c3"]
 eng = bench.HipEngine()
 dem, bufs, outs, N = eng.build(wl, dev, 20251004)
 nwg = 4096
-stamps = torch.zeros(4 * nwg, dtype=torch.int64, device=dev)
+stamps = torch.zeros(8 * nwg, dtype=torch.int64, device=dev)
 st = torch.cuda.Stream(dev)
 for k in range(3000):     # reach the power-capped steady state first
     dem.process_device(bufs[k % 8], outs[0], st)
@@ -27,7 +27,7 @@ for k in range(6):
     for j in range(20):
         dem.process_device(bufs[j % 8], outs[0], st)
     torch.cuda.synchronize()
-    s = stamps.cpu().numpy().reshape(-1, 4)
+    s = stamps.cpu().numpy().reshape(-1, 8)
     s = s[s[:, 0] > 0]
     t0, t1, xcc, hwid = s[:, 0] * 0.01, s[:, 1] * 0.01, s[:, 2] & 0xf, s[:, 2] >> 8      # us
     base = t0.min()
@@ -61,6 +61,16 @@ for k in range(6):
         first_w = collections.Counter(sorted(v)[0][1] for v in g2.values() if len(v) == 2)
         print("wave_id of the workgroup that ends first:", dict(first_w))
         print("end-time histogram (us):", np.histogram(t1 - base, bins=10)[0].tolist(), np.round(np.histogram(t1 - base, bins=10)[1], 1).tolist())
+    if s[:, 3].max() > 0:      # slot 3: end of the assembly block (ring16 kernel)
+        t3 = s[:, 3] * 0.01
+        late = t0 - base > 2.0      # workgroups of the second round
+        d["asm_end_minus_start_us"] = dict(round1=round(float((t3 - t0)[~late].mean()), 2), round2=round(float((t3 - t0)[late].mean()), 2) if late.any() else None)
+        d["end_minus_asm_end_us"] = dict(round1=round(float((t1 - t3)[~late].mean()), 2), round2=round(float((t1 - t3)[late].mean()), 2) if late.any() else None)
+        if s[:, 4].max() > 0:  # slot 4: just before the assembly block
+            t4 = s[:, 4] * 0.01
+            d["asm_start_minus_start_us"] = dict(round1=round(float((t4 - t0)[~late].mean()), 2), round2=round(float((t4 - t0)[late].mean()), 2) if late.any() else None)
+        d["round2_wgs"] = int(late.sum())
+        d["round2_start_us"] = [round(float((t0 - base)[late].min()), 1), round(float((t0 - base)[late].max()), 1)] if late.any() else None
     print(json.dumps(d))
 dbg.gsdr_debug_set_stamp_buffer(None)
 dem.close()

@@ -646,6 +646,8 @@ CHIRP_CASES = [
     (200_000_000, -100_000_000, 100_000_000, 1_000_000, 30.0, 0, 20_000, 2),  # period > 2^32: 64-bit path
     (200_000_000, -100_000_000, 100_000_000, 1_000_000, 30.0, 1, 20_000, 3),  # same with lock-in, ppt 6000
     (1_000_000, -400_000, 400_000, 10, 1e-5, 3, 1000, 3),               # length 1, ppt 3 < 64 lanes
+    (200_000_000, -80_000_000, 80_000_000, 1000, 3e-3, 3, 50_000, 4),   # length 600, ppt 1800: three 256-sample
+                                                                        # stretches per step, three steps per point
 ]
 
 
