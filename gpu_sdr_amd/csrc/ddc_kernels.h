@@ -92,7 +92,7 @@ struct MfmaLaunch {
     const float2 *ptab;        // [ceil(nk8/KS)][NT32*32]  w_n^(hi*PK)
     const float2 *dtab;        // [32][NT32*32]            w_n^(row*M)
     const unsigned *fmod;      // [NT32*32]
-    const unsigned *maxbits;   // [slots][16] absmax slots (16 partial maxima each)
+    const unsigned *maxbits;   // [slots][kAbsmaxPartials] absmax slots (partial maxima of the staging pass)
     float2 *out;
     const uint4 *img;          // AsmRing16P: [ngt][nhi] pre-converted ring-slot images of 8 KiB (ddc_convert_kernel)
     MfmaShape sh;
@@ -109,6 +109,8 @@ void mfma_build_tables(const MfmaPlan &pl, const std::vector<unsigned> &fmod_in,
                        std::vector<uint4> &bfrag, std::vector<float2> &ptab,
                        std::vector<float2> &dtab, std::vector<float> &taps,
                        std::vector<unsigned> &fmod, float &unscale);
+// partial maxima per absmax slot (the workgroups of the staging pass fold theirs into them)
+constexpr int kAbsmaxPartials = 128;
 hipError_t launch_absmax(const float2 *x, long long n, unsigned *slots, int cur, int next,
                          float2 *head_cur, long long head_n, float2 *head_next, int carry_len,
                          float2 *tail, long long tail0, hipStream_t st, const float2 *extra_src = nullptr,

@@ -142,17 +142,39 @@ __device__ __forceinline__ void stamp(int slot) {
 __device__ __forceinline__ void stamp(int) {}
 #endif
 
-// max |component| over this and the previous buffer: absmax_kernel keeps 16 partial
-// maxima per slot (float bits of non-negative numbers order like unsigned integers)
-__device__ __forceinline__ unsigned slot_max(const unsigned *slots, int cur, int prev) {
-    unsigned m = 0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const unsigned a = slots[cur * 16 + i], b = slots[prev * 16 + i];
-        const unsigned t = a > b ? a : b;
-        m = m > t ? m : t;
+// max |component| over this and the previous buffer.  absmax_kernel folds the maxima of its workgroups
+// into the kAbsmaxPartials addresses of its slot (float bits of non-negative numbers order like
+// unsigned integers) with atomicMax, at most four workgroups per address: same-address atomics
+// serialise at ~100 ns each -- with 16 addresses they cost the pass 1.6 us of its 6, a single address
+// would cost 25 (tools/ubench_read.hip).  Every wave reduces the two slots for itself: one 8-byte
+// load per lane and slot (a wider slot costs registers the assembly kernels do not have: the
+// pre-converted-operand kernel dropped to one wave per SIMD with 512 partials), then a DPP butterfly.
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    int x = (int)v;
+#define GSDR_DPP_MAX(ctrl, row_mask)                                                          \
+    {                                                                                         \
+        const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, x, ctrl, row_mask, 0xf, false); \
+        x = (int)((unsigned)x > o ? (unsigned)x : o);                                         \
     }
-    return m;
+    GSDR_DPP_MAX(0xB1, 0xf);    // quad_perm [1,0,3,2]
+    GSDR_DPP_MAX(0x4E, 0xf);    // quad_perm [2,3,0,1]
+    GSDR_DPP_MAX(0x141, 0xf);   // row_half_mirror
+    GSDR_DPP_MAX(0x140, 0xf);   // row_mirror
+    GSDR_DPP_MAX(0x142, 0xa);   // row_bcast:15
+    GSDR_DPP_MAX(0x143, 0xc);   // row_bcast:31: lane 63 holds the maximum
+#undef GSDR_DPP_MAX
+    return (unsigned)__builtin_amdgcn_readlane(x, 63);
+}
+
+__device__ __forceinline__ unsigned slot_max(const unsigned *slots, int cur, int prev) {
+    static_assert(kAbsmaxPartials == 128, "one 8-byte load per lane and slot");
+    unsigned tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = (int)(tid & 63u);
+    const uint2 a = reinterpret_cast<const uint2 *>(slots + (size_t)cur * kAbsmaxPartials)[lane];
+    const uint2 b = reinterpret_cast<const uint2 *>(slots + (size_t)prev * kAbsmaxPartials)[lane];
+    const unsigned u = a.x > a.y ? a.x : a.y, w = b.x > b.y ? b.x : b.y;
+    return wave_max_u32(u > w ? u : w);
 }
 
 // w_n^(idx_base + 32*gt*M): the phasor of tone n (fm = f_n mod rate) at the first row of
@@ -946,17 +968,17 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float2 *x, long long 
         const unsigned t = (unsigned)__shfl_xor((int)m, d);
         m = m > t ? m : t;
     }
-    // one atomic per workgroup: thousands of same-address atomics serialise
+    // one atomic per workgroup, kAbsmaxPartials addresses per slot (see slot_max); workgroup 0 clears
+    // the slot of the next call
     __shared__ unsigned wmax[4];
     if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned u = wmax[0] > wmax[1] ? wmax[0] : wmax[1], w = wmax[2] > wmax[3] ? wmax[2] : wmax[3];
         const unsigned t = u > w ? u : w;
-        // 16 addresses per slot: same-address atomics serialise (~10 ns each)
-        if (t) atomicMax(&slots[cur * 16 + (blockIdx.x & 15)], t);
+        if (t) atomicMax(&slots[(size_t)cur * kAbsmaxPartials + (blockIdx.x % kAbsmaxPartials)], t);
     }
-    if (blockIdx.x == 0 && threadIdx.x < 16) slots[next * 16 + threadIdx.x] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x < kAbsmaxPartials) slots[(size_t)next * kAbsmaxPartials + threadIdx.x] = 0u;
 }
 
 // ---------------------------------------------------------------------------
@@ -1104,14 +1126,14 @@ hipError_t launch_absmax(const float2 *x, long long n, unsigned *slots, int cur,
     if (n < 1 || carry_len < 0 || carry_len > n || head_n < 0 || head_n > n || tail0 < 0 || tail0 > n ||
         extra_n < 0 || (extra_n > 0 && (!extra_src || !extra_dst)))
         return hipErrorInvalidValue;
-    // samples per workgroup (GSDR_ABSMAX_CHUNK, default 4096), at most 1024 workgroups, even chunks
+    // samples per workgroup (GSDR_ABSMAX_CHUNK, default 2048), at most 4 * kAbsmaxPartials workgroups, even chunks
     static const long long want = [] {
         const char *e = std::getenv("GSDR_ABSMAX_CHUNK");
-        const long long v = e ? std::atoll(e) : 4096;
-        return v >= 512 ? v : 4096;
+        const long long v = e ? std::atoll(e) : 2048;
+        return v >= 512 ? v : 2048;
     }();
     long long blocks = (n + want - 1) / want;
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > 4 * kAbsmaxPartials) blocks = 4 * kAbsmaxPartials;
     if (blocks < 1) blocks = 1;
     long long chunk = (n + blocks - 1) / blocks;
     chunk += chunk & 1;

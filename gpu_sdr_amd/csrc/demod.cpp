@@ -418,8 +418,8 @@ int setup_mfma(gsdr_demod *h, bool direct, const std::vector<long long> &tone) {
     HIPCHK(h, upload(&h->d_dtab, dtab));
     HIPCHK(h, upload(&h->d_mtaps, taps));
     HIPCHK(h, upload(&h->d_mfmod, fmod));
-    HIPCHK(h, dev_alloc(&h->d_maxbits, kScaleSlots * 16));   // slots of 16 partial maxima
-    HIPCHK(h, hipMemset(h->d_maxbits, 0, kScaleSlots * 16 * sizeof(unsigned)));
+    HIPCHK(h, dev_alloc(&h->d_maxbits, kScaleSlots * gsdr::kAbsmaxPartials));   // slots of partial maxima
+    HIPCHK(h, hipMemset(h->d_maxbits, 0, kScaleSlots * gsdr::kAbsmaxPartials * sizeof(unsigned)));
     gsdr::MfmaShape &sh = h->mf;
     sh.N = h->ddc_channels;
     sh.NT32 = pl.ntg * pl.TT;

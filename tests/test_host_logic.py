@@ -238,3 +238,34 @@ def test_generated_loops_obey_the_hazard_rules(tmp_path):
         bad.write_text("\n".join(lines[:at] + [text] + lines[at:]))
         errs = chk.check(str(bad))
         assert any(f" {rule}:" in e for e in errs), (rule, errs[:3])
+
+
+def test_assembly_kernels_keep_two_waves_per_simd(gsdr_lib, tmp_path):
+    """The matrix-core kernels are scheduled for two waves per SIMD (512 registers per lane: at most
+    256 VGPRs + AGPRs per wave).  C++ around the assembly block that needs a few registers too many
+    makes the compiler park them in extra AGPRs, the kernel still runs -- at one wave per SIMD and
+    10 % slower (it happened with a wider absmax slot).  Read the register counts out of the code
+    object of the library as built."""
+    import shutil
+    import subprocess
+    from gpu_sdr_amd import _lib
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(os.path.join(llvm, "llvm-objdump")):
+        pytest.skip("no ROCm llvm tools")
+    so = tmp_path / "libgsdr.so"
+    shutil.copy(_lib.LIB_PATH, so)
+    subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", str(so)], check=True, capture_output=True, cwd=tmp_path)
+    seen = {}
+    for f in tmp_path.iterdir():
+        if "amdgcn" not in f.name:
+            continue
+        notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", str(f)], check=True, capture_output=True, text=True).stdout
+        for blk in notes.split("- .agpr_count:")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", blk)
+            vg = re.search(r"\.vgpr_count:\s+(\d+)", blk)
+            if name and vg:
+                seen[name.group(1)] = int(vg.group(1))       # .vgpr_count is VGPRs + AGPRs on gfx90a and later
+    asm_kernels = [k for k in seen if re.search(r"ddc_mfma_ring(16|16w8|16p)?_kernel", k)]
+    assert len(asm_kernels) == 4, sorted(seen)
+    for k in asm_kernels:
+        assert seen[k] <= 256, (k, seen[k])

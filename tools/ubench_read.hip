@@ -48,6 +48,45 @@ __global__ __launch_bounds__(256) void k_read16(const float2 *x, float *o, long 
     if ((threadIdx.x & 63) == 0) o[blockIdx.x * 4 + (threadIdx.x >> 6)] = acc;
 }
 
+// the staging pass's tail: the workgroup's maximum into one of `slots` addresses with atomicMax
+// (slots = 0: a plain store of the partial, one address per workgroup)
+template <int SLOTS>
+__global__ __launch_bounds__(256) void k_read16_max(const float2 *x, float *o, long long n) {
+    const float4 *x4 = reinterpret_cast<const float4 *>(x);
+    const long long n4 = n / 2, stride = (long long)gridDim.x * 256;
+    unsigned m = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += 4 * stride) {
+        float4 q[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[k] = i + k * stride < n4 ? x4[i + k * stride] : make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned a = __float_as_uint(q[k].x) & 0x7fffffffu, b = __float_as_uint(q[k].y) & 0x7fffffffu;
+            const unsigned c = __float_as_uint(q[k].z) & 0x7fffffffu, d = __float_as_uint(q[k].w) & 0x7fffffffu;
+            const unsigned u = a > b ? a : b, w = c > d ? c : d;
+            m = m > u ? m : u;
+            m = m > w ? m : w;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned t = (unsigned)__shfl_xor((int)m, off, 64);
+        m = m > t ? m : t;
+    }
+    __shared__ unsigned wmax[4];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned u = wmax[0] > wmax[1] ? wmax[0] : wmax[1], w = wmax[2] > wmax[3] ? wmax[2] : wmax[3];
+        const unsigned t = u > w ? u : w;
+        unsigned *slots = reinterpret_cast<unsigned *>(o);
+        if (SLOTS > 0)
+            atomicMax(&slots[blockIdx.x % (SLOTS > 0 ? SLOTS : 1)], t);
+        else
+            slots[blockIdx.x] = t;
+    }
+}
+
 template <typename K>
 float run(K k, int grid, float2 **bufs, float *o, long long n) {
     hipEvent_t a, b;
@@ -82,5 +121,15 @@ int main() {
         t = run(k_read16, grid, bufs, o, n);
         printf("read16   grid %4d: %.2f us per launch  %.2f TB/s\n", grid, t, mb / t);
     }
+    t = run(k_read16_max<16>, 245, bufs, o, n);
+    printf("read16 + max, 16 atomic addresses, grid 245: %.2f us per launch\n", t);
+    t = run(k_read16_max<64>, 245, bufs, o, n);
+    printf("read16 + max, 64 atomic addresses, grid 245: %.2f us per launch\n", t);
+    t = run(k_read16_max<0>, 245, bufs, o, n);
+    printf("read16 + max, plain store per workgroup, grid 245: %.2f us per launch\n", t);
+    t = run(k_read16_max<0>, 489, bufs, o, n);
+    printf("read16 + max, plain store per workgroup, grid 489: %.2f us per launch\n", t);
+    t = run(k_read16_max<0>, 977, bufs, o, n);
+    printf("read16 + max, plain store per workgroup, grid 977: %.2f us per launch\n", t);
     return 0;
 }
