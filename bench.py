@@ -529,6 +529,12 @@ def rooflines(wl, r, key, period_s=None):
                     executed_mfma_tflops=round(mtfl, 1),
                     executed_mfma_frac=round(mtfl / F16_MFMA_PEAK_TFLOPS, 4),
                     frac_of_fp32_vector_peak=round(tfl / FP32_PEAK_TFLOPS, 4), **common)
+    elif r["kernel"] == "pfb_lds_kernel":
+        # TONES as the reference does it: polyphase filter + FFT + bin selection, a frame per workgroup
+        # inside the LDS.  A few flops per byte (4 f + 5 log2 nfft per sample): HBM-bound -- one read of
+        # the window, one write of the selected bins.
+        roof = dict(roof_hbm, note="polyphase filter + in-LDS FFT + bin selection (the reference's own algorithm): "
+                                   "HBM-bound; algorithmic bytes = 8 B read per sample + 8 B per selected bin and frame")
     elif wl["kind"] in ("direct", "pfb"):
         # packed-FP32 DDC (GSDR_DDC_MFMA=0): FP32-compute bound. The FP32
         # vector peak equals the FP32 (f32-input) MFMA peak on gfx950: 157.3 TF.
@@ -653,7 +659,7 @@ def main(argv=None, engine=None):
     # where the tensors of barrier()/max_over_ranks() live: on the GPU for RCCL, on the CPU for gloo
     ctl_device = device if (dist is None or backend == "nccl") else None
 
-    api = args.api if args.api != "auto" else ("pipelined" if wl["kind"] in ("direct", "pfb") else "inorder")
+    api = args.api if args.api != "auto" else ("pipelined" if wl["kind"] == "direct" else "inorder")
 
     m = _measure_with_ctl(engine, args.workload, device, ctl_device, seed, args.steps, args.warmup, dist, api,
                           args.min_seconds)
@@ -697,7 +703,7 @@ def main(argv=None, engine=None):
                 if key == args.workload:
                     continue
                 ek = WORKLOADS[key]
-                eapi = "pipelined" if ek["kind"] in ("direct", "pfb") else "inorder"
+                eapi = "pipelined" if ek["kind"] == "direct" else "inorder"   # only the matrix-core DDC overlaps buffers
                 e = measure(engine, key, device, seed, steps=500, warmup=50, dist=None, api=eapi, min_seconds=0.5)
                 er = e["r"]
                 extras[key] = dict(workload=ek["name"], msamples_per_s=round(e["value"], 2), api=er["api"],

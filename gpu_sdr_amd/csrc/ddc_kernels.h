@@ -140,6 +140,19 @@ hipError_t fft_forward(const FftPlan &pl, float2 *src, float2 *dst, float2 *tmp,
 hipError_t launch_pfb_filter(const float2 *raw, const float *window, int nfft, int avg, int frames_n, float2 *frames,
                              hipStream_t st);
 const char *fft_kernel_name();
+// The whole PFB of a frame in one workgroup (filter, in-LDS transform, bin selection): frames of up to
+// kPfbLdsMaxN points whose prime factors do not exceed kPfbLdsMaxPrime.
+constexpr int kPfbLdsMaxN = 8192;
+constexpr int kPfbLdsMaxPrime = 127;
+constexpr int kPfbLdsTwMaxN = 4096;                       // up to here the twiddle table sits in the LDS as well
+constexpr int kPfbLdsMaxBytes = (2 * kPfbLdsMaxN + kPfbLdsMaxPrime + 1) * 8;   // two frame buffers + roots: 129 KiB of the 160 KiB
+int pfb_lds_plan(int n, int *radices16);                 // number of stages, -1 when the length does not fit
+// logical window [carry (new_0 samples) | in (window_len - new_0)]; frames_n complete frames -> out[frame][n_out]
+// (sel: bin per output column, nullptr = all nfft bins); W[spare_begin .. +spare_n) -> carry_out
+hipError_t launch_pfb_lds(const float2 *carry, int new_0, const float2 *in, const float *window, const float2 *tw,
+                          int nfft, int avg, int frames_n, const int *sel, int n_out, float2 *out,
+                          float2 *carry_out, int spare_begin, int spare_n, long long window_len, hipStream_t st);
+const char *pfb_lds_kernel_name();
 
 // ---- chirp ---------------------------------------------------------------
 struct ChirpShape {

@@ -148,6 +148,11 @@ struct gsdr_demod {
     gsdr::FftPlan fft{};
     float2 *d_fft_a = nullptr, *d_fft_b = nullptr;   // frames / scratch, batching * max(nfft, m) each
     float *d_fft_win = nullptr;                      // the PFB window on the device
+    // ---- TONES / NOISE, a frame per workgroup: filter + in-LDS transform + bin selection (fft_kernels.hip) ----
+    bool pfb_lds = false;
+    float2 *d_pfb_tw = nullptr;                      // w_nfft^k
+    int *d_pfb_sel = nullptr;                        // TONES: bin of every output column
+    float2 *d_pfb_carry[kStageSets] = {};            // the samples a call leaves over (at most F*nfft)
     // ---- CHIRP ----
     ChirpShape cs{};
     int ppt = 0;
@@ -793,8 +798,34 @@ int enqueue_noise_fft(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t 
     return ret;
 }
 
+// ref: process_pfb (:486-565) and process_pfb_spec (:568-649), decim == 0: one launch, a frame per
+// workgroup.  The logical raw_input is [what the previous call left over | the new buffer]; nothing is
+// staged: the kernel reads both parts in place and writes this call's leftovers (:504-509, :590-596)
+// into the other carry buffer.
+int enqueue_pfb_lds(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t st) {
+    const int cb = h->bh.current_batch;
+    const float2 *carry = h->d_pfb_carry[h->win_seq % kStageSets];
+    float2 *carry_out = h->d_pfb_carry[(h->win_seq + 1) % kStageSets];
+    const int spare_n = h->bh.spare_samples > 0 ? h->bh.spare_samples : 0;
+    if (spare_n > h->nfft * h->F) {
+        h->err = "PFB carry larger than a window";
+        return -1;
+    }
+    hipEvent_t stop = nullptr;
+    if (record_begin(h, st, &stop)) return -1;
+    HIPCHK(h, gsdr::launch_pfb_lds(carry, h->bh.new_0, in, h->d_fft_win, h->d_pfb_tw, h->nfft, h->F, cb,
+                                   h->mode == GSDR_NOISE ? nullptr : h->d_pfb_sel, h->ddc_channels, out, carry_out,
+                                   h->bh.spare_begin, spare_n, (long long)h->bh.new_0 + h->L, st));
+    if (stop) HIPCHK(h, hipEventRecord(stop, st));
+    h->win_seq++;
+    const int ret = h->ddc_channels * cb;  // :546 (TONES), copy_size :638 (NOISE)
+    gsdr_buffer_helper_update(&h->bh);     // :552 / :644
+    return ret;
+}
+
 // ref: process_pfb (decim == 0 branch), cpp/USRP_demodulator.cpp:486-565
 int enqueue_pfb(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t st) {
+    if (h->pfb_lds) return enqueue_pfb_lds(h, in, out, st);
     if (h->noise_fft) return enqueue_noise_fft(h, in, out, st);
     // :491-495  new buffer goes after the carried samples
     const int cb = h->bh.current_batch;
@@ -1053,6 +1084,35 @@ gsdr_demod *gsdr_demod_create(const gsdr_param_c *p) {
             // buffer_helper(n_tones, buffer_len, average, n_eff_tones): :159 / :301
             gsdr_buffer_helper_init(&h->bh, h->nfft, (int)h->L, F, n_ch);
             h->ddc_channels = n_ch;
+            // A frame per workgroup -- polyphase filter, transform inside the LDS, bin selection: the
+            // reference's own algorithm (:486-565, :568-649) at one read of the window and one write of
+            // the selected bins per buffer.  Frames of up to 8192 points without a prime factor above 127;
+            // GSDR_PFB_LDS=0, GSDR_TONES_FFT=0 (TONES only) or such a length leave TONES to the DDC
+            // kernels (every selected bin as a tone) and NOISE to the global-memory FFT stages.
+            int radices16[16];
+            const bool lds_path = env_int("GSDR_PFB_LDS", 1) != 0 && gsdr::pfb_lds_plan(h->nfft, radices16) >= 0 &&
+                                  (noise ? noise_fft : env_int("GSDR_TONES_FFT", 1) != 0);
+            if (lds_path) {
+                h->pfb_lds = true;
+                h->F = F;
+                h->M = h->nfft;
+                h->kernel_name = gsdr::pfb_lds_kernel_name();
+                std::vector<float2> tw((size_t)h->nfft);
+                for (int k = 0; k < h->nfft; ++k) {
+                    const double a = -2.0 * M_PI * (double)k / (double)h->nfft;
+                    tw[(size_t)k] = make_float2((float)std::cos(a), (float)std::sin(a));
+                }
+                std::vector<int> sel(tone.begin(), tone.end());
+                bool ok = upload(&h->d_pfb_tw, tw) == hipSuccess && upload(&h->d_fft_win, h->window) == hipSuccess &&
+                          (noise || upload(&h->d_pfb_sel, sel) == hipSuccess);
+                const size_t ncarry = (size_t)h->nfft * F + 8;
+                for (int i = 0; i < kStageSets && ok; ++i)
+                    ok = dev_alloc(&h->d_pfb_carry[i], ncarry) == hipSuccess &&
+                         hipMemset(h->d_pfb_carry[i], 0, ncarry * sizeof(float2)) == hipSuccess;
+                if (!need(ok, "PFB allocation failed")) return nullptr;
+                h->capacity = (long long)n_ch * h->batching;               // :147 / :288
+                break;
+            }
             if (noise_fft) {
                 h->noise_fft = true;
                 h->F = F;
@@ -1462,6 +1522,10 @@ void gsdr_demod_close(gsdr_demod *h) {
     if (h->d_fft_a) (void)hipFree(h->d_fft_a);
     if (h->d_fft_b) (void)hipFree(h->d_fft_b);
     if (h->d_fft_win) (void)hipFree(h->d_fft_win);
+    if (h->d_pfb_tw) (void)hipFree(h->d_pfb_tw);
+    if (h->d_pfb_sel) (void)hipFree(h->d_pfb_sel);
+    for (int i = 0; i < kStageSets; ++i)
+        if (h->d_pfb_carry[i]) (void)hipFree(h->d_pfb_carry[i]);
     if (h->stream) (void)hipStreamDestroy(h->stream);  // ref: 03_implement.md:58-63
     delete h;
 }
@@ -1531,7 +1595,8 @@ int gsdr_demod_describe(const gsdr_demod *h, char *buf, int cap) {
     s += "\", \"kernel\": \"";
     s += h->kernel_name;
     s += "\", \"family\": \"";
-    s += h->noise_fft ? "fp32 Stockham FFT behind the polyphase filter" : h->mfma ? "f16 MFMA, hi/lo split" : (h->mode == GSDR_CHIRP ? "fp32 VALU, integer phase" : (h->pipe ? "packed fp32 VALU" : "fp32 VALU"));
+    s += h->pfb_lds ? "polyphase filter + fp32 Stockham FFT inside the LDS + bin selection, one launch" :
+         h->noise_fft ? "fp32 Stockham FFT behind the polyphase filter" : h->mfma ? "f16 MFMA, hi/lo split" : (h->mode == GSDR_CHIRP ? "fp32 VALU, integer phase" : (h->pipe ? "packed fp32 VALU" : "fp32 VALU"));
     s += "\", \"channels\": " + std::to_string(h->ddc_channels > 0 ? h->ddc_channels : h->N);
     s += ", \"row_tiles_per_workgroup\": " + std::to_string(h->mfma ? h->last_rt : 0);
     s += ", \"pipeline_streams\": " + std::to_string(h->pipe_ready ? h->pipe_streams : env_int("GSDR_PIPE_STREAMS", kPipeStreams));

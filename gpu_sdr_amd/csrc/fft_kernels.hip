@@ -161,6 +161,258 @@ __global__ __launch_bounds__(256) GSDR_NO_PK void bluestein_post_kernel(const fl
     out[g] = mk2(r.x * inv, r.y * inv);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The whole PFB of a frame in one workgroup (TONES and NOISE with fft_tones <= kPfbLdsMaxN):
+// polyphase filter -> Stockham stages between two LDS buffers -> bin selection -> output.
+// ref: process_pfb / process_pfb_spec, cpp/USRP_demodulator.cpp:486-565, :568-649 (polyphase_filter
+// kernels.cu:474-516, cufftExecC2C, tone_select kernels.cu:520-554).  Per 1 Mi-sample buffer that is
+// one read of the window (every sample F times, the repeats out of L2) and one write of the
+// selected bins: HBM-bound, a few flops per byte -- no staging copy of the buffer, no pass through
+// memory per radix stage.  The logical window is [carry | in]: the samples the previous call left
+// over, then the new buffer; the last workgroups of the grid copy this call's leftovers to the
+// carry of the next one.
+// ---------------------------------------------------------------------------------------------
+struct PfbLdsArgs {
+    const float2 *carry;       // new_0 samples left over by the previous call
+    const float2 *in;          // the new buffer
+    const float *window;       // [F][n] taps
+    const float2 *tw;          // w_n^k, k < n
+    const int *sel;            // selected bins (nullptr: all n bins)
+    float2 *out;               // [frames_n][n_out]
+    float2 *carry_out;         // receives W[spare_begin .. spare_begin + spare_n)
+    int n, F, frames_n, n_out, new_0, FR;
+    int spare_begin, spare_n;
+    unsigned main_blocks;
+    int n_radices;
+    int radices[16];
+    // x / d as umulhi(x, magic(d)) (0: d == 1), exact while x * d < 2^32 -- every quotient of the kernel
+    // is of an index below 2^17 by a divisor of at most 2^13.  A runtime integer division is ~30 vector
+    // instructions; with one or two per butterfly the kernel was bound by them.
+    unsigned mag_n, mag_nout;
+    unsigned mag_t[16], mag_p[16];     // per stage: t = n / R, p = product of the earlier radices
+    unsigned mag_t4, mag_rt4;          // prime-first stage: t4 = ceil(t / 4), R * t4
+};
+
+__device__ __forceinline__ int fdiv(int x, unsigned magic) {
+    return magic ? (int)__umulhi((unsigned)x, magic) : x;
+}
+
+__device__ __forceinline__ float2 pfb_window_at(const PfbLdsArgs &a, int q) {
+    const float2 *p = q < a.new_0 ? a.carry + q : a.in + (q - a.new_0);
+    return *p;
+}
+
+template <int R>
+__device__ __forceinline__ void lds_stage(const float2 *src, float2 *dst, int n, int p, unsigned mag_t, unsigned mag_p,
+                                          const float2 *__restrict__ tw, int FR, int tid) {
+    const int t = n / R, tws = n / (p * R);      // uniform: scalar divisions
+    for (int g = tid; g < FR * t; g += 256) {
+        const int fr = FR == 1 ? 0 : fdiv(g, mag_t), i = g - fr * t;
+        const int k = i - fdiv(i, mag_p) * p;
+        const int j = (i - k) * R + k;
+        const float2 *xb = src + fr * n;
+        float2 *yb = dst + fr * n;
+        float2 u[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) u[r] = xb[i + r * t];
+        if (p != 1) {                             // the first stage has no twiddles in front (k == 0)
+            const int kt = k * tws;
+#pragma unroll
+            for (int r = 1; r < R; ++r) u[r] = cmul(u[r], tw[r * kt]);
+        }
+        butterfly<R>(u, tw, n);
+#pragma unroll
+        for (int r = 0; r < R; ++r) yb[j + r * p] = u[r];
+    }
+}
+
+// A larger prime radix R as the FIRST stage (p = 1: no twiddles in front of the butterfly),
+//     out[i R + q] = sum_r x[i + r t] w_R^(q r),   t = n / R,
+// one q and four consecutive i per work item: the root of a term is read once for four products
+// (5 LDS reads per 4 complex MACs; one (i, q) per item with the roots from the global table was bound
+// by load latency: 41 of 1230 = 2*3*5*41 cost 40 us per buffer).  roots: w_R^m, m < R, in the LDS.
+__device__ __forceinline__ void lds_stage_prime_first(int R, const float2 *src, float2 *dst, int n, const float2 *roots,
+                                                      unsigned mag_t4, unsigned mag_rt4, int FR, int tid) {
+    const int t = n / R, t4 = (t + 3) >> 2;
+    for (int g = tid; g < FR * R * t4; g += 256) {
+        const int fr = FR == 1 ? 0 : fdiv(g, mag_rt4), rem = g - fr * (R * t4);
+        const int q = fdiv(rem, mag_t4), i0 = (rem - q * t4) << 2;
+        // clamp instead of branching: lanes beyond t redo the last column and do not store
+        // (offsets, not pointers: a pointer that is advanced in the loop loses its LDS address space and
+        //  the reads become flat loads)
+        int off[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) off[c] = fr * n + (i0 + c < t ? i0 + c : t - 1);
+        float2 acc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = src[off[c]];
+        int idx = 0;
+        for (int r = 1; r < R; ++r) {
+            idx += q;
+            idx = idx >= R ? idx - R : idx;
+            const float2 w = roots[idx];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                off[c] += t;
+                const float2 x = src[off[c]];
+                acc[c].x = fmaf(x.x, w.x, fmaf(-x.y, w.y, acc[c].x));
+                acc[c].y = fmaf(x.x, w.y, fmaf(x.y, w.x, acc[c].y));
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (i0 + c < t) dst[fr * n + (i0 + c) * R + q] = acc[c];
+    }
+}
+
+// any further prime radix above 13 (two large prime factors in one length: rare): one output per work
+// item, out[q] = sum_r x[i + r t] w_n^(r (k tws + q n/R)), roots from the twiddle table
+__device__ __forceinline__ void lds_stage_generic(int R, const float2 *src, float2 *dst, int n, int p,
+                                                  const float2 *__restrict__ tw, int FR, int tid) {
+    const int t = n / R, tws = n / (p * R), nr = n / R;
+    for (int g = tid; g < FR * t * R; g += 256) {
+        const int fr = g / (t * R), rem = g - fr * (t * R);
+        const int q = rem / t, i = rem - q * t;
+        const int k = i % p;
+        const int j = (i - k) * R + k;
+        const float2 *xb = src + fr * n + i;
+        const int e = (int)(((long long)k * tws + (long long)q * nr) % n);
+        float2 acc = xb[0];
+        int idx = 0;
+        for (int r = 1; r < R; ++r) {
+            idx += e;
+            if (idx >= n) idx -= n;
+            const float2 v = cmul(xb[r * t], tw[idx]);
+            acc.x += v.x;
+            acc.y += v.y;
+        }
+        dst[fr * n + j + q * p] = acc;
+    }
+}
+
+// TWL: the twiddle table w_n^k is copied into the LDS first (frames of up to kPfbLdsTwMaxN points); the
+// stages then find their factors at LDS latency instead of one L1 round trip per stage
+template <bool TWL>
+__global__ __launch_bounds__(256) GSDR_NO_PK void pfb_lds_kernel(const PfbLdsArgs a) {
+    extern __shared__ float2 pfb_lds[];
+    const int tid = threadIdx.x, n = a.n, FR = a.FR;
+    if (blockIdx.x >= a.main_blocks) {
+        // leftovers of this call -> carry of the next one
+        const int j0 = (int)(blockIdx.x - a.main_blocks) * 2048;
+        for (int j = j0 + tid; j < j0 + 2048 && j < a.spare_n; j += 256)
+            a.carry_out[j] = pfb_window_at(a, a.spare_begin + j);
+        return;
+    }
+    float2 *A = pfb_lds, *B = pfb_lds + (size_t)FR * n, *roots = pfb_lds + (size_t)2 * FR * n;
+    float2 *twl = roots + (kPfbLdsMaxPrime + 1);
+    const int f0 = (int)blockIdx.x * FR;
+    // polyphase filter: float accumulate in tap order (as pfb_filter_kernel).  Four points per thread and
+    // up to four taps at a time: their 16 + 16 loads are issued before the first product (a loop of
+    // load -> multiply-add is one memory round trip per tap and point: 4 us of a 1024-point frame).
+    // The twiddle table and the roots of a large first radix (w_R^m = w_n^(m n/R)) travel with the
+    // first batch of loads.
+    const int R0 = a.n_radices > 0 && a.radices[0] > 13 ? a.radices[0] : 0;
+    // the parameters of stage s live in lane s of three registers
+    const int st_lane = tid & 15;
+    const int st_radix = a.radices[st_lane], st_mag_t = (int)a.mag_t[st_lane], st_mag_p = (int)a.mag_p[st_lane];
+    // the bins of the first output columns of this thread: loaded now, used behind the last stage
+    int sel0[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int idx = tid + 256 * c;
+        const int fr = FR == 1 ? 0 : fdiv(idx, a.mag_nout);
+        const int u = idx - fr * a.n_out;
+        sel0[c] = a.sel && idx < FR * a.n_out ? a.sel[u] : u;
+    }
+    bool first = true;
+    for (int base = tid; base < FR * n; base += 1024) {
+        int kk[4], q0[4];
+        bool ok[4];
+        float2 acc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int idx = base + 256 * c;
+            const int idc = idx < FR * n ? idx : FR * n - 1;
+            const int fr = FR == 1 ? 0 : fdiv(idc, a.mag_n);
+            kk[c] = idc - fr * n;
+            ok[c] = idx < FR * n && f0 + fr < a.frames_n;
+            q0[c] = ok[c] ? (f0 + fr) * n + kk[c] : 0;       // W[0] is always there
+            acc[c] = mk2(0.f, 0.f);
+        }
+        for (int i0 = 0; i0 < a.F; i0 += 4) {
+            float2 sm[4][4];
+            float wv[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = i0 + j < a.F ? i0 + j : a.F - 1;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    sm[c][j] = pfb_window_at(a, q0[c] + (ok[c] ? i * n : 0));
+                    wv[c][j] = a.window[i * n + kk[c]];
+                }
+            }
+            if (first) {
+                first = false;
+                if (TWL)
+                    for (int k = tid; k < n; k += 256) twl[k] = a.tw[k];
+                for (int m = tid; m < R0; m += 256) roots[m] = a.tw[m * (n / R0)];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (i0 + j < a.F) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        acc[c].x += sm[c][j].x * wv[c][j];
+                        acc[c].y += sm[c][j].y * wv[c][j];
+                    }
+                }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (base + 256 * c < FR * n) A[base + 256 * c] = ok[c] ? acc[c] : mk2(0.f, 0.f);
+    }
+    __syncthreads();
+    const float2 *tw = TWL ? twl : a.tw;
+    float2 *src = A, *dst = B;
+    int p = 1;
+    for (int s = 0; s < a.n_radices; ++s) {
+        // (a.radices[s] with a running s is a scalar load and its latency in every stage)
+        const int R = __builtin_amdgcn_readlane(st_radix, s);
+        const unsigned mt = (unsigned)__builtin_amdgcn_readlane(st_mag_t, s), mp = (unsigned)__builtin_amdgcn_readlane(st_mag_p, s);
+        switch (R) {
+            case 2: lds_stage<2>(src, dst, n, p, mt, mp, tw, FR, tid); break;
+            case 3: lds_stage<3>(src, dst, n, p, mt, mp, tw, FR, tid); break;
+            case 4: lds_stage<4>(src, dst, n, p, mt, mp, tw, FR, tid); break;
+            case 5: lds_stage<5>(src, dst, n, p, mt, mp, tw, FR, tid); break;
+            case 7: lds_stage<7>(src, dst, n, p, mt, mp, tw, FR, tid); break;
+            case 11: lds_stage<11>(src, dst, n, p, mt, mp, tw, FR, tid); break;
+            case 13: lds_stage<13>(src, dst, n, p, mt, mp, tw, FR, tid); break;
+            default:
+                if (s == 0)
+                    lds_stage_prime_first(R, src, dst, n, roots, a.mag_t4, a.mag_rt4, FR, tid);
+                else
+                    lds_stage_generic(R, src, dst, n, p, tw, FR, tid);
+                break;
+        }
+        __syncthreads();
+        p *= R;
+        float2 *t2 = src;
+        src = dst;
+        dst = t2;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int idx = tid + 256 * c;
+        const int fr = FR == 1 ? 0 : fdiv(idx, a.mag_nout), u = idx - fr * a.n_out;
+        if (idx < FR * a.n_out && f0 + fr < a.frames_n) a.out[(size_t)(f0 + fr) * a.n_out + u] = src[fr * n + sel0[c]];
+    }
+    for (int idx = tid + 1024; idx < FR * a.n_out; idx += 256) {
+        const int fr = FR == 1 ? 0 : fdiv(idx, a.mag_nout), u = idx - fr * a.n_out;
+        const int r = f0 + fr;
+        if (r < a.frames_n) a.out[(size_t)r * a.n_out + u] = src[fr * n + (a.sel ? a.sel[u] : u)];
+    }
+}
+
 inline unsigned grid_for(long long total) { return (unsigned)((total + 255) / 256); }
 
 template <int R>
@@ -349,6 +601,93 @@ hipError_t launch_pfb_filter(const float2 *raw, const float *window, int nfft, i
     return hipGetLastError();
 }
 
+// Stages of the in-LDS transform: 4s, 2, then every odd prime factor (3, 5, 7 with register
+// butterflies, any larger prime through the one-output-per-item stage).  Empty when n does not fit:
+// n > kPfbLdsMaxN, more than 16 stages, or a prime factor above kPfbLdsMaxPrime (its stage is O(R) per
+// output: a 1021-point prime frame would be a plain DFT).
+int pfb_lds_plan(int n, int *radices) {
+    if (n < 1 || n > kPfbLdsMaxN) return -1;
+    int cnt = 0, m = n;
+    auto push = [&](int r) { if (cnt < 16) radices[cnt] = r; ++cnt; };
+    // prime factors above 13 first, the largest in front (its stage then needs no twiddles)
+    int small = 1;
+    for (int q : {2, 3, 5, 7, 11, 13})
+        while (m % q == 0) { small *= q; m /= q; }
+    int big[16], nbig = 0;
+    for (int q = 17; q <= m; q += 2)
+        while (m % q == 0) {
+            if (q > kPfbLdsMaxPrime || nbig == 16) return -1;
+            big[nbig++] = q;
+            m /= q;
+        }
+    if (m != 1) return -1;
+    for (int i = nbig - 1; i >= 0; --i) push(big[i]);
+    m = small;
+    while (m % 4 == 0) { push(4); m /= 4; }
+    for (int q : {2, 3, 5, 7, 11, 13})
+        while (m % q == 0) { push(q); m /= q; }
+    return cnt <= 16 ? cnt : -1;
+}
+
+hipError_t launch_pfb_lds(const float2 *carry, int new_0, const float2 *in, const float *window, const float2 *tw,
+                          int nfft, int avg, int frames_n, const int *sel, int n_out, float2 *out,
+                          float2 *carry_out, int spare_begin, int spare_n, long long window_len, hipStream_t st) {
+    PfbLdsArgs a{};
+    a.n_radices = pfb_lds_plan(nfft, a.radices);
+    if (a.n_radices < 0 || avg < 1 || frames_n < 0 || n_out < 1 || new_0 < 0 || spare_n < 0 || spare_begin < 0 ||
+        !in || !window || !tw || !out || (new_0 > 0 && !carry) || (spare_n > 0 && !carry_out) || (!sel && n_out != nfft))
+        return hipErrorInvalidValue;
+    // every read stays inside the logical window [carry | in]
+    if ((frames_n > 0 && (long long)(frames_n + avg - 1) * nfft > window_len) ||
+        (long long)spare_begin + spare_n > window_len || new_0 > window_len)
+        return hipErrorInvalidValue;
+    a.carry = carry; a.in = in; a.window = window; a.tw = tw; a.sel = sel; a.out = out; a.carry_out = carry_out;
+    a.n = nfft; a.F = avg; a.frames_n = frames_n; a.n_out = n_out; a.new_0 = new_0;
+    a.spare_begin = spare_begin; a.spare_n = spare_n;
+    // short frames share a workgroup: at least ~1024 points of work per workgroup
+    a.FR = nfft >= 1024 ? 1 : (1024 + nfft - 1) / nfft;
+    if (a.FR > 64) a.FR = 64;
+    a.main_blocks = (unsigned)((frames_n + a.FR - 1) / a.FR);
+    if (window_len > 0x7fffffffLL - nfft) return hipErrorInvalidValue;     // 32-bit window positions in the kernel
+    auto magic = [](long long d) { return d <= 1 ? 0u : (unsigned)(0x100000000ULL / (unsigned long long)d + 1ULL); };
+    a.mag_n = magic(nfft);
+    a.mag_nout = magic(n_out);
+    {
+        int p = 1;
+        for (int s = 0; s < a.n_radices; ++s) {
+            a.mag_t[s] = magic(nfft / a.radices[s]);
+            a.mag_p[s] = magic(p);
+            p *= a.radices[s];
+        }
+        if (a.n_radices > 0 && a.radices[0] > 13) {
+            const int t4 = (nfft / a.radices[0] + 3) / 4;
+            a.mag_t4 = magic(t4);
+            a.mag_rt4 = magic((long long)a.radices[0] * t4);
+        }
+    }
+    const unsigned spare_blocks = (unsigned)((spare_n + 2047) / 2048);
+    if (a.main_blocks + spare_blocks == 0) return hipSuccess;
+    const bool twl = nfft <= kPfbLdsTwMaxN;
+    const size_t lds = ((size_t)2 * a.FR * nfft + kPfbLdsMaxPrime + 1 + (twl ? nfft : 0)) * sizeof(float2);   // two frame sets + roots (+ twiddles)
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(pfb_lds_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kPfbLdsMaxBytes);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(pfb_lds_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, kPfbLdsMaxBytes);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    if (lds > (size_t)kPfbLdsMaxBytes) return hipErrorInvalidValue;
+    if (twl)
+        hipLaunchKernelGGL(pfb_lds_kernel<true>, dim3(a.main_blocks + spare_blocks), dim3(256), lds, st, a);
+    else
+        hipLaunchKernelGGL(pfb_lds_kernel<false>, dim3(a.main_blocks + spare_blocks), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+const char *pfb_lds_kernel_name() { return "pfb_lds_kernel"; }
 const char *fft_kernel_name() { return "fft_pass_kernel"; }
 
 }  // namespace gsdr

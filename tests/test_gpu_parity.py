@@ -74,11 +74,18 @@ def make_chirp(rate, f0, f1, steps, t, decim, L):
     return g.RX_buffer_demodulator(p, device_index=0)
 
 
-@pytest.fixture(params=["flat", "mfma", "mfma_rt2", "mfma16", "mfma16w8", "mfma16p"])
+@pytest.fixture(params=["default", "flat", "mfma", "mfma_rt2", "mfma16", "mfma16w8", "mfma16p"])
 def engine(request, monkeypatch):
-    """Runs a test once per DDC engine: packed-FP32 VALU kernel; round 1's matrix-core kernel (32x32x16
-    MFMA; one / two row tiles per workgroup); the 16x16x32 ring loop, its eight-wave build and its
-    pre-converted-operand build."""
+    """Runs a test once per engine: "default" = the library as shipped, no variable set (per-launch
+    kernel choice for the DDC; TONES through the filter + in-LDS FFT kernel); then the DDC engines,
+    forced, with TONES on the DDC kernels too (every selected bin as a tone, GSDR_TONES_FFT=0):
+    packed-FP32 VALU kernel; round 1's matrix-core kernel (32x32x16 MFMA; one / two row tiles per
+    workgroup); the 16x16x32 ring loop, its eight-wave build and its pre-converted-operand build."""
+    if request.param == "default":
+        for k in [k for k in os.environ if k.startswith("GSDR_")]:
+            monkeypatch.delenv(k)
+        return request.param
+    monkeypatch.setenv("GSDR_TONES_FFT", "0")
     monkeypatch.setenv("GSDR_DDC_MFMA", "0" if request.param == "flat" else "1")
     monkeypatch.setenv("GSDR_MFMA_ASM", {"mfma16": "4", "mfma16w8": "5", "mfma16p": "4"}.get(request.param, "2"))
     monkeypatch.setenv("GSDR_MFMA_PREC", "1" if request.param == "mfma16p" else "0")
@@ -91,6 +98,7 @@ def mfma_engine(request, monkeypatch):
     """Matrix-core DDC: round 1's loop on the 32x32x16 MFMA / the ring loop on the 16x16x32 shape /
     its eight-wave build / its pre-converted-operand build."""
     monkeypatch.setenv("GSDR_DDC_MFMA", "1")
+    monkeypatch.setenv("GSDR_TONES_FFT", "0")
     monkeypatch.setenv("GSDR_MFMA_ASM", {"x16": "4", "x16w8": "5", "x16p": "4"}.get(request.param, "2"))
     monkeypatch.setenv("GSDR_MFMA_PREC", "1" if request.param == "x16p" else "0")
     return request.param
@@ -568,21 +576,41 @@ NOISE_FFT_CASES = [
     (2, 4, 50_000, 2),
     (4099, 3, 60_000, 3),                      # prime: Bluestein through 16384
     (8192, 4, 100_000, 2),                     # 4^6 * 2
+    (127 * 8, 2, 40_000, 3),                   # 1016: the largest first-stage prime of the in-LDS kernel
+    (17 * 19 * 4, 3, 30_000, 3),               # 1292: two primes above 13 (19 first, 17 through the generic stage)
+    (48, 8, 300, 6),                           # frames longer than a buffer: calls without a frame; 22 frames per workgroup
+    (131 * 4, 2, 20_000, 2),                   # 524: prime factor 131 > 127 -> not for the in-LDS kernel
 ]
 
 
+def pfb_lds_fits(nfft):
+    """lengths the frame-per-workgroup kernel takes: <= 8192 points, no prime factor above 127"""
+    m, q, largest = nfft, 2, 1
+    while m > 1:
+        while m % q == 0:
+            m //= q
+            largest = q
+        q += 1
+    return nfft <= 8192 and largest <= 127
+
+
+@pytest.mark.parametrize("path", ["lds", "global"])
 @pytest.mark.parametrize("nfft,avg,L,nbuf", NOISE_FFT_CASES, ids=lambda v: str(v))
-def test_noise_fft_stage_parity(cuda_device, gsdr_lib, oracle_mod, nfft, avg, L, nbuf):
-    """NOISE through the hand-written FFT stage (csrc/fft_kernels.hip): polyphase filter, then a
-    batched forward FFT of every complete frame -- mixed-radix Stockham stages, Bluestein for
-    lengths with a prime factor above 13 -- against the oracle's fp64 DFT of every bin.  Frame
-    counts per call and the carry of unconsumed samples are exact."""
+def test_noise_fft_stage_parity(cuda_device, gsdr_lib, oracle_mod, monkeypatch, nfft, avg, L, nbuf, path):
+    """NOISE through the hand-written FFT (csrc/fft_kernels.hip) against the oracle's fp64 DFT of every
+    bin.  "lds": the library's choice -- polyphase filter, transform and output of a frame in one
+    workgroup, inside the LDS (up to 8192 points, prime factors up to 127: a large prime is the first
+    stage); other lengths fall to the second path.  "global" (GSDR_PFB_LDS=0): polyphase filter kernel,
+    then one launch per Stockham stage through memory, Bluestein for lengths with a prime factor above 13.
+    Frame counts per call and the carry of unconsumed samples are exact."""
     import gpu_sdr_amd as g
+    if path == "global":
+        monkeypatch.setenv("GSDR_PFB_LDS", "0")
     rng = np.random.default_rng(4100 + nfft)
     p = g.param(mode="RX", rate=1_000_000, buffer_len=L, decim=0, pf_average=avg, fft_tones=nfft,
                 freq=[0], wave_type=[g.w_type.NOISE])
     dem = g.RX_buffer_demodulator(p, device_index=0)
-    assert dem.kernel_name == "fft_pass_kernel"
+    assert dem.kernel_name == ("pfb_lds_kernel" if path == "lds" and pfb_lds_fits(nfft) else "fft_pass_kernel")
     ref = oracle_mod.Noise(nfft, avg, L)
     assert dem.out_capacity == nfft * ref.batching
     for c in range(nbuf):
@@ -989,20 +1017,24 @@ def test_pipelined_submit_device_overlapping_buffers(cuda_device, gsdr_lib, orac
     b.close()
 
 
-@pytest.mark.parametrize("streams", ["2", "3"])
+@pytest.mark.parametrize("streams", ["2", "3", "fft"])
 def test_pipelined_submit_device_tones(cuda_device, gsdr_lib, oracle_mod, monkeypatch, streams):
-    """TONES through gsdr_demod_submit_device: the raw windows of consecutive buffers are
-    separate (the staging pass of a call copies the unconsumed end of the previous window),
-    so their kernels overlap too.  L is no multiple of nfft: the carried length changes from
-    buffer to buffer.  Bit-equal to the in-order entry, within tolerance of the oracle."""
+    """TONES through gsdr_demod_submit_device.  On the DDC kernels (GSDR_TONES_FFT=0; 2 / 3 compute
+    streams) the raw windows of consecutive buffers are separate (the staging pass of a call copies
+    the unconsumed end of the previous window), so their kernels overlap too; "fft": the library's
+    own choice, the frame-per-workgroup kernel with its two carry buffers.  L is no multiple of nfft:
+    the carried length changes from buffer to buffer.  Bit-equal to the in-order entry, within
+    tolerance of the oracle."""
     import torch
     monkeypatch.setenv("GSDR_DDC_MFMA", "1")
-    monkeypatch.setenv("GSDR_PIPE_STREAMS", streams)
+    if streams != "fft":
+        monkeypatch.setenv("GSDR_TONES_FFT", "0")
+        monkeypatch.setenv("GSDR_PIPE_STREAMS", streams)
     rate, nfft, F, L, N = 10_000_000, 250, 4, 100_003, 96
     rng = np.random.default_rng(2718)
     freq = rng.choice(np.arange(-rate // 2 + 1, rate // 2), size=N, replace=False)
     a, b = make_pfb(freq, rate, nfft, F, L), make_pfb(freq, rate, nfft, F, L)
-    assert b.kernel_name.startswith("ddc_mfma")
+    assert b.kernel_name == "pfb_lds_kernel" if streams == "fft" else b.kernel_name.startswith("ddc_mfma")
     ref = oracle_mod.Pfb(freq, rate, nfft, F, L)
     scales = [1.0, 1e-3, 50.0, 1.0, 1e-2, 1.0, 7.0, 1.0, 1.0]
     xs = [torch.from_numpy((crandn(rng, L) * np.float32(sc)).astype(np.complex64)).to(cuda_device) for sc in scales]
@@ -1103,15 +1135,18 @@ def test_pipelined_entry_limits(cuda_device, gsdr_lib):
     dem.close()
 
 
-@pytest.mark.parametrize("rt", ["0", "2"])
-def test_pipelined_fuzz_random_shapes(cuda_device, gsdr_lib, monkeypatch, rt):
+@pytest.mark.parametrize("rt,tones", [("0", "ddc"), ("2", "ddc"), ("0", "fft")])
+def test_pipelined_fuzz_random_shapes(cuda_device, gsdr_lib, monkeypatch, rt, tones):
     """Seeded fuzz of the overlapped device entry against the in-order entry, bit for bit:
     DIRECT and TONES shapes nobody picked by hand (one row tile, partial last tiles, windows of
     one block, buffers barely longer than the carry, batch counts that change from buffer to
-    buffer), seven buffers each with up to four outstanding."""
+    buffer), seven buffers each with up to four outstanding.  TONES on the DDC kernels
+    (GSDR_TONES_FFT=0) or through the frame-per-workgroup kernel (the library's choice)."""
     import torch
     monkeypatch.setenv("GSDR_DDC_MFMA", "1")
     monkeypatch.setenv("GSDR_MFMA_RT", rt)
+    if tones == "ddc":
+        monkeypatch.setenv("GSDR_TONES_FFT", "0")
     rng = np.random.default_rng(4242)
     ran_mfma = 0
     for it in range(36):
@@ -1128,7 +1163,9 @@ def test_pipelined_fuzz_random_shapes(cuda_device, gsdr_lib, monkeypatch, rt):
             L = int(M * rng.integers(max(F, 4), 400))
             mk = lambda: make_direct(freq, rate, M, F, L)
         a, b = mk(), mk()
-        ran_mfma += b.kernel_name.startswith("ddc_mfma")
+        ran_mfma += b.kernel_name.startswith("ddc_mfma") or b.kernel_name == "pfb_lds_kernel"
+        if it % 3 == 2 and tones == "fft":
+            assert b.kernel_name == "pfb_lds_kernel"
         xs = [torch.from_numpy((crandn(rng, L) * np.float32(10.0 ** rng.integers(-3, 3))).astype(np.complex64))
               .to(cuda_device) for _ in range(7)]
         out_a = torch.empty(a.out_capacity, dtype=torch.complex64, device=cuda_device)

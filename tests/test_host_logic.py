@@ -269,3 +269,11 @@ def test_assembly_kernels_keep_two_waves_per_simd(gsdr_lib, tmp_path):
     assert len(asm_kernels) == 4, sorted(seen)
     for k in asm_kernels:
         assert seen[k] <= 256, (k, seen[k])
+    # and no kernel of the library spills to scratch or reads through the flat aperture: an LDS pointer
+    # that is advanced in a loop silently turns ds_read into flat_load (it did, in the in-LDS FFT: +50 %)
+    for f in tmp_path.iterdir():
+        if "amdgcn" not in f.name:
+            continue
+        dis = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", str(f)], check=True, capture_output=True, text=True).stdout
+        bad = [ln.strip() for ln in dis.splitlines() if re.search(r"\b(flat_load|flat_store|scratch_load|scratch_store)", ln)]
+        assert not bad, (f.name, bad[:4])
