@@ -172,6 +172,17 @@ __global__ __launch_bounds__(256) GSDR_NO_PK void bluestein_post_kernel(const fl
 // over, then the new buffer; the last workgroups of the grid copy this call's leftovers to the
 // carry of the next one.
 // ---------------------------------------------------------------------------------------------
+// Diagnostic builds only (-DGSDR_STAMP_BUILD, scratch/stamp_pfb.py): every workgroup leaves the times
+// (s_memrealtime, 100 MHz) of its phases in a buffer of its own; the shipped library has none of this.
+#ifdef GSDR_STAMP_BUILD
+__device__ unsigned long long *g_fft_stamp_buf = nullptr;
+__device__ __forceinline__ void fft_stamp(int slot) {
+    if (g_fft_stamp_buf && threadIdx.x == 0) g_fft_stamp_buf[8 * (size_t)blockIdx.x + slot] = __builtin_amdgcn_s_memrealtime();
+}
+#else
+__device__ __forceinline__ void fft_stamp(int) {}
+#endif
+
 struct PfbLdsArgs {
     const float2 *carry;       // new_0 samples left over by the previous call
     const float2 *in;          // the new buffer
@@ -227,41 +238,65 @@ __device__ __forceinline__ void lds_stage(const float2 *src, float2 *dst, int n,
 }
 
 // A larger prime radix R as the FIRST stage (p = 1: no twiddles in front of the butterfly),
-//     out[i R + q] = sum_r x[i + r t] w_R^(q r),   t = n / R,
-// one q and four consecutive i per work item: the root of a term is read once for four products
-// (5 LDS reads per 4 complex MACs; one (i, q) per item with the roots from the global table was bound
-// by load latency: 41 of 1230 = 2*3*5*41 cost 40 us per buffer).  roots: w_R^m, m < R, in the LDS.
-__device__ __forceinline__ void lds_stage_prime_first(int R, const float2 *src, float2 *dst, int n, const float2 *roots,
-                                                      unsigned mag_t4, unsigned mag_rt4, int FR, int tid) {
-    const int t = n / R, t4 = (t + 3) >> 2;
-    for (int g = tid; g < FR * R * t4; g += 256) {
-        const int fr = FR == 1 ? 0 : fdiv(g, mag_rt4), rem = g - fr * (R * t4);
+//     out[i R + q] = sum_r x[i + r t] w_R^(q r),   t = n / R.
+// The terms r and R - r are taken together, x_r w^(qr) + x_(R-r) w^(-qr) = S_r cos - i D_r sin with
+// S_r = x_r + x_(R-r), D_r = x_r - x_(R-r) (formed once, in place, by a first pass), and the two sums
+//     A = sum_(r <= h) S_r cos(2 pi q r / R),   B = sum_(r <= h) D_r sin(2 pi q r / R),   h = (R - 1) / 2,
+// give two outputs, out[q] = x_0 + A - iB and out[R - q] = x_0 + A + iB: a quarter of the multiply-adds
+// of the plain sum (which cost 11 of the 27 us of a 1230 = 41*2*3*5-point buffer).  One q and four
+// consecutive columns i per work item; roots: w_R^m = (cos, -sin)(2 pi m / R), m < R, in the LDS.
+__device__ __forceinline__ void lds_stage_prime_first(int R, float2 *src, float2 *dst, int n, const float2 *roots,
+                                                      unsigned mag_t, unsigned mag_t4, unsigned mag_rt4, int FR, int tid) {
+    const int t = n / R, t4 = (t + 3) >> 2, h = (R - 1) >> 1;
+    // pass 1: S and D in place
+    for (int g = tid; g < FR * h * t; g += 256) {
+        const int rr = fdiv(g, mag_t), i = g - rr * t;          // rr = fr * h + (r - 1)
+        const int fr = FR == 1 ? 0 : rr / h, r = rr - fr * h + 1;
+        const int lo = fr * n + i + r * t, hi = fr * n + i + (R - r) * t;
+        const float2 x = src[lo], y = src[hi];
+        src[lo] = mk2(x.x + y.x, x.y + y.y);
+        src[hi] = mk2(x.x - y.x, x.y - y.y);
+    }
+    __syncthreads();
+    // pass 2: q = 0 .. h; work item = (frame, q, group of four columns)
+    const int items = (h + 1) * t4;
+    (void)mag_rt4;
+    for (int g = tid; g < FR * items; g += 256) {
+        const int fr = FR == 1 ? 0 : g / items, rem = g - fr * items;
         const int q = fdiv(rem, mag_t4), i0 = (rem - q * t4) << 2;
-        // clamp instead of branching: lanes beyond t redo the last column and do not store
-        // (offsets, not pointers: a pointer that is advanced in the loop loses its LDS address space and
-        //  the reads become flat loads)
         int off[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) off[c] = fr * n + (i0 + c < t ? i0 + c : t - 1);
-        float2 acc[4];
+        for (int c = 0; c < 4; ++c) off[c] = fr * n + (i0 + c < t ? i0 + c : t - 1);   // lanes beyond t redo the last column
+        float2 x0[4], A[4], B[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] = src[off[c]];
+        for (int c = 0; c < 4; ++c) {
+            x0[c] = src[off[c]];
+            A[c] = mk2(0.f, 0.f);
+            B[c] = mk2(0.f, 0.f);
+        }
         int idx = 0;
-        for (int r = 1; r < R; ++r) {
+        for (int r = 1; r <= h; ++r) {
             idx += q;
             idx = idx >= R ? idx - R : idx;
-            const float2 w = roots[idx];
+            const float2 w = roots[idx];             // (cos, -sin)
+            const float cs = w.x, sn = -w.y;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                off[c] += t;
-                const float2 x = src[off[c]];
-                acc[c].x = fmaf(x.x, w.x, fmaf(-x.y, w.y, acc[c].x));
-                acc[c].y = fmaf(x.x, w.y, fmaf(x.y, w.x, acc[c].y));
+                const float2 S = src[off[c] + r * t], D = src[off[c] + (R - r) * t];
+                A[c].x = fmaf(S.x, cs, A[c].x);
+                A[c].y = fmaf(S.y, cs, A[c].y);
+                B[c].x = fmaf(D.x, sn, B[c].x);
+                B[c].y = fmaf(D.y, sn, B[c].y);
             }
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-            if (i0 + c < t) dst[fr * n + (i0 + c) * R + q] = acc[c];
+            if (i0 + c < t) {
+                const int o = fr * n + (i0 + c) * R;
+                const float bx = x0[c].x + A[c].x, by = x0[c].y + A[c].y;
+                dst[o + q] = mk2(bx + B[c].y, by - B[c].x);
+                if (q != 0) dst[o + R - q] = mk2(bx - B[c].y, by + B[c].x);
+            }
     }
 }
 
@@ -303,6 +338,7 @@ __global__ __launch_bounds__(256) GSDR_NO_PK void pfb_lds_kernel(const PfbLdsArg
             a.carry_out[j] = pfb_window_at(a, a.spare_begin + j);
         return;
     }
+    fft_stamp(0);
     float2 *A = pfb_lds, *B = pfb_lds + (size_t)FR * n, *roots = pfb_lds + (size_t)2 * FR * n;
     float2 *twl = roots + (kPfbLdsMaxPrime + 1);
     const int f0 = (int)blockIdx.x * FR;
@@ -325,6 +361,8 @@ __global__ __launch_bounds__(256) GSDR_NO_PK void pfb_lds_kernel(const PfbLdsArg
         sel0[c] = a.sel && idx < FR * a.n_out ? a.sel[u] : u;
     }
     bool first = true;
+    const bool all_in = f0 * n >= a.new_0 && a.frames_n - f0 >= FR;     // uniform; q >= new_0 for every read then
+    const float2 *in_base = a.in - a.new_0;
     for (int base = tid; base < FR * n; base += 1024) {
         int kk[4], q0[4];
         bool ok[4];
@@ -336,7 +374,7 @@ __global__ __launch_bounds__(256) GSDR_NO_PK void pfb_lds_kernel(const PfbLdsArg
             const int fr = FR == 1 ? 0 : fdiv(idc, a.mag_n);
             kk[c] = idc - fr * n;
             ok[c] = idx < FR * n && f0 + fr < a.frames_n;
-            q0[c] = ok[c] ? (f0 + fr) * n + kk[c] : 0;       // W[0] is always there
+            q0[c] = ok[c] ? (f0 + fr) * n + kk[c] : a.new_0; // W[new_0] = in[0] is always there
             acc[c] = mk2(0.f, 0.f);
         }
         for (int i0 = 0; i0 < a.F; i0 += 4) {
@@ -347,8 +385,11 @@ __global__ __launch_bounds__(256) GSDR_NO_PK void pfb_lds_kernel(const PfbLdsArg
                 const int i = i0 + j < a.F ? i0 + j : a.F - 1;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    sm[c][j] = pfb_window_at(a, q0[c] + (ok[c] ? i * n : 0));
-                    wv[c][j] = a.window[i * n + kk[c]];
+                    const int q = q0[c] + (ok[c] ? i * n : 0);
+                    // (a workgroup whose frames lie behind the carried samples reads the buffer through one
+                    //  uniform base and 32-bit offsets; the select of pfb_window_at() is 64-bit arithmetic per load)
+                    sm[c][j] = all_in ? in_base[(unsigned)q] : pfb_window_at(a, q);
+                    wv[c][j] = a.window[(unsigned)(i * n + kk[c])];
                 }
             }
             if (first) {
@@ -372,6 +413,7 @@ __global__ __launch_bounds__(256) GSDR_NO_PK void pfb_lds_kernel(const PfbLdsArg
             if (base + 256 * c < FR * n) A[base + 256 * c] = ok[c] ? acc[c] : mk2(0.f, 0.f);
     }
     __syncthreads();
+    fft_stamp(1);
     const float2 *tw = TWL ? twl : a.tw;
     float2 *src = A, *dst = B;
     int p = 1;
@@ -389,12 +431,13 @@ __global__ __launch_bounds__(256) GSDR_NO_PK void pfb_lds_kernel(const PfbLdsArg
             case 13: lds_stage<13>(src, dst, n, p, mt, mp, tw, FR, tid); break;
             default:
                 if (s == 0)
-                    lds_stage_prime_first(R, src, dst, n, roots, a.mag_t4, a.mag_rt4, FR, tid);
+                    lds_stage_prime_first(R, src, dst, n, roots, mt, a.mag_t4, a.mag_rt4, FR, tid);
                 else
                     lds_stage_generic(R, src, dst, n, p, tw, FR, tid);
                 break;
         }
         __syncthreads();
+        fft_stamp(2 + (s < 4 ? s : 4));
         p *= R;
         float2 *t2 = src;
         src = dst;
@@ -411,7 +454,9 @@ __global__ __launch_bounds__(256) GSDR_NO_PK void pfb_lds_kernel(const PfbLdsArg
         const int r = f0 + fr;
         if (r < a.frames_n) a.out[(size_t)r * a.n_out + u] = src[fr * n + (a.sel ? a.sel[u] : u)];
     }
+    fft_stamp(7);
 }
+
 
 inline unsigned grid_for(long long total) { return (unsigned)((total + 255) / 256); }
 
@@ -486,6 +531,13 @@ hipError_t to_device(T **dst, const std::vector<T> &src) {
 }
 
 }  // namespace
+
+#ifdef GSDR_STAMP_BUILD
+extern "C" int gsdr_debug_set_fft_stamp_buffer(void *dev_ptr) {
+    unsigned long long *p = (unsigned long long *)dev_ptr;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_fft_stamp_buf), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int fft_plan_build(FftPlan &pl, int n) {
     pl = FftPlan{};
