@@ -193,7 +193,7 @@ struct PfbLdsArgs {
     float2 *carry_out;         // receives W[spare_begin .. spare_begin + spare_n)
     int n, F, frames_n, n_out, new_0, FR;
     int spare_begin, spare_n;
-    unsigned main_blocks;
+    unsigned main_blocks, blocks_per_xcd;
     int n_radices;
     int radices[16];
     // x / d as umulhi(x, magic(d)) (0: d == 1), exact while x * d < 2^32 -- every quotient of the kernel
@@ -331,9 +331,14 @@ template <bool TWL>
 __global__ __launch_bounds__(256) GSDR_NO_PK void pfb_lds_kernel(const PfbLdsArgs a) {
     extern __shared__ float2 pfb_lds[];
     const int tid = threadIdx.x, n = a.n, FR = a.FR;
-    if (blockIdx.x >= a.main_blocks) {
+    // Workgroups are dealt to the 8 XCDs in turn (blockIdx % 8) and each XCD has its own L2.  Frame r
+    // shares (F-1)/F of its samples with frame r+1: give every XCD a contiguous run of frames, so that
+    // the repeats come out of its L2 (with frame = blockIdx every sample was fetched F times over the
+    // fabric: FETCH_SIZE 32 MB per 8 MB buffer).  The grid is padded to a multiple of 8.
+    const unsigned padded = a.blocks_per_xcd * 8u;
+    if (blockIdx.x >= padded) {
         // leftovers of this call -> carry of the next one
-        const int j0 = (int)(blockIdx.x - a.main_blocks) * 2048;
+        const int j0 = (int)(blockIdx.x - padded) * 2048;
         for (int j = j0 + tid; j < j0 + 2048 && j < a.spare_n; j += 256)
             a.carry_out[j] = pfb_window_at(a, a.spare_begin + j);
         return;
@@ -341,7 +346,9 @@ __global__ __launch_bounds__(256) GSDR_NO_PK void pfb_lds_kernel(const PfbLdsArg
     fft_stamp(0);
     float2 *A = pfb_lds, *B = pfb_lds + (size_t)FR * n, *roots = pfb_lds + (size_t)2 * FR * n;
     float2 *twl = roots + (kPfbLdsMaxPrime + 1);
-    const int f0 = (int)blockIdx.x * FR;
+    const unsigned wg = (blockIdx.x & 7u) * a.blocks_per_xcd + (blockIdx.x >> 3);
+    if (wg >= a.main_blocks) return;
+    const int f0 = (int)wg * FR;
     // polyphase filter: float accumulate in tap order (as pfb_filter_kernel).  Four points per thread and
     // up to four taps at a time: their 16 + 16 loads are issued before the first product (a loop of
     // load -> multiply-add is one memory round trip per tap and point: 4 us of a 1024-point frame).
@@ -717,8 +724,10 @@ hipError_t launch_pfb_lds(const float2 *carry, int new_0, const float2 *in, cons
             a.mag_rt4 = magic((long long)a.radices[0] * t4);
         }
     }
+    a.blocks_per_xcd = (a.main_blocks + 7u) / 8u;
     const unsigned spare_blocks = (unsigned)((spare_n + 2047) / 2048);
     if (a.main_blocks + spare_blocks == 0) return hipSuccess;
+    const unsigned grid = a.blocks_per_xcd * 8u + spare_blocks;
     const bool twl = nfft <= kPfbLdsTwMaxN;
     const size_t lds = ((size_t)2 * a.FR * nfft + kPfbLdsMaxPrime + 1 + (twl ? nfft : 0)) * sizeof(float2);   // two frame sets + roots (+ twiddles)
     static bool attr_done = false;
@@ -733,9 +742,9 @@ hipError_t launch_pfb_lds(const float2 *carry, int new_0, const float2 *in, cons
     }
     if (lds > (size_t)kPfbLdsMaxBytes) return hipErrorInvalidValue;
     if (twl)
-        hipLaunchKernelGGL(pfb_lds_kernel<true>, dim3(a.main_blocks + spare_blocks), dim3(256), lds, st, a);
+        hipLaunchKernelGGL(pfb_lds_kernel<true>, dim3(grid), dim3(256), lds, st, a);
     else
-        hipLaunchKernelGGL(pfb_lds_kernel<false>, dim3(a.main_blocks + spare_blocks), dim3(256), lds, st, a);
+        hipLaunchKernelGGL(pfb_lds_kernel<false>, dim3(grid), dim3(256), lds, st, a);
     return hipGetLastError();
 }
 

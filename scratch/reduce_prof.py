@@ -6,6 +6,13 @@ OUT = os.path.join(ROOT, "profiles")
 TAG = "r02"
 
 
+def kname(full):
+    """'void gsdr::(anonymous namespace)::pfb_lds_kernel<true>(...)' -> 'gsdr::pfb_lds_kernel<true>'"""
+    n = full.replace("(anonymous namespace)::", "")
+    n = n[5:] if n.startswith("void ") else n
+    return n.split("(")[0]
+
+
 def newest(pattern):
     fs = glob.glob(pattern, recursive=True)
     return max(fs, key=os.path.getmtime) if fs else None
@@ -16,10 +23,10 @@ def kernel_stats(src_dir, dst):
     if not f:
         return None
     rows = list(csv.reader(open(f)))
-    keep = [rows[0]] + [r for r in rows[1:] if r and r[0].startswith("gsdr::")]
+    keep = [rows[0]] + [r for r in rows[1:] if r and kname(r[0]).startswith("gsdr::")]
     with open(dst, "w", newline="") as o:
         csv.writer(o, quoting=csv.QUOTE_ALL).writerows(keep)
-    return {r[0].split("(")[0]: float(r[3]) / 1e3 for r in keep[1:]}
+    return {kname(r[0]): float(r[3]) / 1e3 for r in keep[1:]}
 
 
 def overlap(src_dir):
@@ -48,7 +55,7 @@ def pmc(src_dir, dst):
         if not f:
             continue
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0]
+            k = kname(r["Kernel_Name"])
             if k.startswith("gsdr::") and "source" not in k:
                 acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     out = {k: {c: round(sum(v) / len(v), 1) for c, v in d.items()} for k, d in acc.items()}
@@ -60,7 +67,7 @@ def dominant(stats):
     """the gsdr:: DDC / chirp kernel with the largest share of the in-order run"""
     best = None
     for k, v in (stats or {}).items():
-        if ("ddc_mfma" in k or "chirp" in k or "ddc_flat" in k) and "convert" not in k:
+        if ("ddc_mfma" in k or "chirp" in k or "ddc_flat" in k or "pfb_lds" in k) and "convert" not in k:
             if best is None or v[1] > best[1]:
                 best = (k, v[1])
     return best[0] if best else None
@@ -72,10 +79,10 @@ def kernel_stats2(src_dir, dst):
     if not f:
         return None
     rows = list(csv.reader(open(f)))
-    keep = [rows[0]] + [r for r in rows[1:] if r and r[0].startswith("gsdr::")]
+    keep = [rows[0]] + [r for r in rows[1:] if r and kname(r[0]).startswith("gsdr::")]
     with open(dst, "w", newline="") as o:
         csv.writer(o, quoting=csv.QUOTE_ALL).writerows(keep)
-    return {r[0].split("(")[0]: (float(r[3]) / 1e3, float(r[2])) for r in keep[1:]}
+    return {kname(r[0]): (float(r[3]) / 1e3, float(r[2])) for r in keep[1:]}
 
 
 traffic = {}
@@ -91,7 +98,7 @@ for wl in ("c2", "c3", "pfb", "c4"):
     c = pm.get(k, {})
     entry = {"kernel_inorder": k, "rocprof_avg_us_inorder": round(st_io[k][0], 2) if st_io and k in st_io else None,
              "overlapped_entry_kernels_avg_us": {kk: round(v[0], 2) for kk, v in (st or {}).items()
-                                                 if "ddc" in kk or "chirp" in kk or "absmax" in kk}}
+                                                 if "ddc" in kk or "chirp" in kk or "absmax" in kk or "pfb" in kk}}
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         entry.update(FETCH_SIZE_KB_raw=c["FETCH_SIZE"], WRITE_SIZE_KB_raw=c["WRITE_SIZE"],
                      hbm_bytes_per_launch=int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024),
