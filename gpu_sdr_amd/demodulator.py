@@ -166,9 +166,11 @@ class RX_buffer_demodulator:
     def kernel_name(self) -> str:
         return self._L.gsdr_demod_kernel_name(self._h).decode()
 
-    def prepare(self, host: bool = True, pipeline: bool = True, pipeline_host: bool = True) -> None:
-        """gsdr_demod_prepare: create now what the entries would create on first use."""
-        what = (1 if host else 0) | (2 if pipeline else 0) | (4 if pipeline_host else 0)
+    def prepare(self, host: bool = True, pipeline: bool = True, pipeline_host: bool = True, rehearse: bool = True) -> None:
+        """gsdr_demod_prepare: create now what the entries would create on first use; `rehearse` also runs a
+        throw-away twin through a few buffers of zeros (the process-wide first-use costs of kernels, pinned
+        copies and streams: 5 - 7 ms each, otherwise paid by the first packets)."""
+        what = (1 if host else 0) | (2 if pipeline else 0) | (4 if pipeline_host else 0) | (8 if rehearse else 0)
         if self._L.gsdr_demod_prepare(self._h, what) != 0:
             raise GsdrError(self._L.gsdr_last_error(self._h).decode())
 

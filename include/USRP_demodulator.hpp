@@ -126,7 +126,7 @@ class RX_buffer_demodulator {
         fcut = gsdr_demod_fcut(handle_);
         // like the reference's constructor (ref: cpp/USRP_demodulator.cpp:59-119): every device
         // buffer and stream exists before the first packet arrives
-        if (gsdr_demod_prepare(handle_, GSDR_PREPARE_HOST | GSDR_PREPARE_PIPELINE | GSDR_PREPARE_PIPELINE_HOST) != 0)
+        if (gsdr_demod_prepare(handle_, GSDR_PREPARE_HOST | GSDR_PREPARE_PIPELINE | GSDR_PREPARE_PIPELINE_HOST | GSDR_PREPARE_REHEARSE) != 0)
             std::fprintf(stderr, "WARNING: demodulator: %s\n", gsdr_last_error(handle_));
         if (diagnostic_) std::fprintf(stderr, "WARNING: Demodulator diagnostic enabled.\n");
     }

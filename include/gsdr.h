@@ -119,6 +119,13 @@ int gsdr_demod_submit_device(gsdr_demod *h, const gsdr_c64 *in_dev, gsdr_c64 *ou
 #define GSDR_PREPARE_HOST 1           /* gsdr_demod_process                  */
 #define GSDR_PREPARE_PIPELINE 2       /* gsdr_demod_submit_device / _wait    */
 #define GSDR_PREPARE_PIPELINE_HOST 4  /* gsdr_demod_submit / _wait           */
+/* GSDR_PREPARE_REHEARSE: also runs a throw-away twin of this demodulator (same parameters) through a
+ * few buffers of zeros on every entry, then closes it.  The first launches of a kernel, the first
+ * asynchronous copies from a pinned buffer and the first uses of a stream cost the process 5 - 7 ms
+ * each, once (measured: calls 0, 1 and 6 of the first handle's submit() loop; later handles of the
+ * process show none): the rehearsal pays them at set-up time, so that the first packets are not late.
+ * The state of `h` itself (carry, NCO phase, call count) is untouched. */
+#define GSDR_PREPARE_REHEARSE 8
 int gsdr_demod_prepare(gsdr_demod *h, int what);
 
 /* ref: RX_buffer_demodulator::close, cpp/USRP_demodulator.cpp:333 (+ :466-698).

@@ -94,14 +94,14 @@ def test_rx_link_tones_against_oracle(cuda_device, gsdr_lib, oracle_mod, tmp_pat
 
 def test_rx_link_first_calls_are_not_late(cuda_device, gsdr_lib):
     """The throughput harness (synthetic RX thread, pinned pools, streamer stand-in): with
-    everything created in the constructor (gsdr_demod_prepare) no call of the pipelined loop
-    may take ten buffer periods, as round 1's did (47-49 ms on the first calls)."""
+    everything created in the constructor and the process-wide first-use costs paid there by a
+    rehearsal (gsdr_demod_prepare with GSDR_PREPARE_REHEARSE), no call of the pipelined loop may take
+    a buffer period -- round 1's first calls took ten (47-49 ms), round 2's before the rehearsal
+    one and a half (5 - 7 ms on calls 0, 1 and 6)."""
     p = subprocess.run([RX_LINK, "256", "100", "300", "pipe"], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     info = json.loads(p.stdout.strip().splitlines()[-1])
     assert info["streamed_samples"] == 300 * (1_000_000 // 100) * 256
-    # 1 M samples at 200 Msps = 5 ms per buffer.  No call may cost as much as the pipeline can
-    # hold (GSDR_PIPELINE_DEPTH = 4 buffers = 20 ms), and once the first calls are through
-    # none may cost a buffer period
-    assert info["worst_ms"] < 20.0, info
+    # 1 M samples at 200 Msps = 5 ms per buffer
+    assert info["worst_ms"] < 5.0, info
     assert info["worst_ms_after_first_8_calls"] < 5.0, info
