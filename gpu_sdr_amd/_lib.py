@@ -104,6 +104,7 @@ SIGNATURES = [
     ("gsdr_vna_helper_update", None, [C.POINTER(VnaHelperC)]),
     ("gsdr_pfb_tone_bins", None, [C.c_int, C.c_int, _ip, C.c_int, _ip]),
     ("gsdr_pfb_batching", C.c_int, [C.c_longlong, C.c_int, C.c_longlong]),
+    ("gsdr_pfb_lds_stages", C.c_int, [C.c_int, C.POINTER(C.c_int)]),
     ("gsdr_chirp_derive", None, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                  C.POINTER(ChirpParamC)]),
     ("gsdr_command_parse", _vp, [C.c_char_p, C.c_int]),

@@ -1577,6 +1577,14 @@ void gsdr_demod_close(gsdr_demod *h) {
     delete h;
 }
 
+int gsdr_pfb_lds_stages(int fft_tones, int *radices) {
+    int tmp[16];
+    const int n = gsdr::pfb_lds_plan(fft_tones, tmp);
+    if (radices)
+        for (int i = 0; i < n && i < 16; ++i) radices[i] = tmp[i];
+    return n;
+}
+
 int gsdr_demod_mode(const gsdr_demod *h) { return h ? h->mode : -1; }
 int gsdr_demod_channels(const gsdr_demod *h) { return h ? h->N : 0; }
 long long gsdr_demod_out_capacity(const gsdr_demod *h) { return h ? h->capacity : 0; }

@@ -17,6 +17,7 @@
 //     m per frame, the transform of the chirp computed once in double on the host.  j^2 mod 2n
 //     is exact in 64-bit integers, so the chirp has no phase drift at any n.
 // Error against an fp64 DFT: a few 1e-7 relative (tests/test_gpu_parity.py), bar 1e-5.
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <vector>
@@ -730,15 +731,18 @@ hipError_t launch_pfb_lds(const float2 *carry, int new_0, const float2 *in, cons
     const unsigned grid = a.blocks_per_xcd * 8u + spare_blocks;
     const bool twl = nfft <= kPfbLdsTwMaxN;
     const size_t lds = ((size_t)2 * a.FR * nfft + kPfbLdsMaxPrime + 1 + (twl ? nfft : 0)) * sizeof(float2);   // two frame sets + roots (+ twiddles)
-    static bool attr_done = false;
-    if (!attr_done) {
+    // (a function attribute belongs to the device it was set on: once per device of this process)
+    static std::atomic<unsigned long long> attr_done{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return hipErrorInvalidDevice;
+    if (!(attr_done.load() >> dev & 1ULL)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(pfb_lds_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kPfbLdsMaxBytes);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(pfb_lds_kernel<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, kPfbLdsMaxBytes);
         if (e != hipSuccess) return e;
-        attr_done = true;
+        attr_done.fetch_or(1ULL << dev);
     }
     if (lds > (size_t)kPfbLdsMaxBytes) return hipErrorInvalidValue;
     if (twl)

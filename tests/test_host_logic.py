@@ -277,3 +277,37 @@ def test_assembly_kernels_keep_two_waves_per_simd(gsdr_lib, tmp_path):
         dis = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", str(f)], check=True, capture_output=True, text=True).stdout
         bad = [ln.strip() for ln in dis.splitlines() if re.search(r"\b(flat_load|flat_store|scratch_load|scratch_store)", ln)]
         assert not bad, (f.name, bad[:4])
+
+
+def test_pfb_lds_stage_plan(gsdr_lib):
+    """gsdr_pfb_lds_stages: the radices of the in-LDS transform multiply to the frame length, prime
+    factors above 13 come first (the largest in front: its stage needs no twiddles), then 4s, 2, and the
+    small odd primes; lengths above 8192 points or with a prime factor above 127 are refused (they take
+    the other paths)."""
+    def stages(n):
+        r = (C.c_int * 16)()
+        k = gsdr_lib.gsdr_pfb_lds_stages(n, r)
+        return None if k < 0 else [r[i] for i in range(k)]
+    assert stages(1) == []
+    assert stages(1024) == [4] * 5
+    assert stages(2048) == [4] * 5 + [2]
+    assert stages(1230) == [41, 2, 3, 5]
+    assert stages(17 * 19 * 4) == [19, 17, 4]
+    assert stages(127 * 8) == [127, 4, 2]
+    assert stages(8192) == [4] * 6 + [2]
+    assert stages(131 * 4) is None and stages(8193) is None and stages(16384) is None and stages(0) is None
+    assert stages(4099) is None                      # prime above 127
+    for n in range(1, 8193):
+        st = stages(n)
+        if st is None:
+            m, q = n, 2
+            while q * q <= m:
+                while m % q == 0:
+                    m //= q
+                q += 1
+            assert m > 127, n                       # only a large prime factor keeps a length out
+            continue
+        assert int(np.prod(st, dtype=np.int64)) == n if st else n == 1
+        big = [r for r in st if r > 13]
+        assert st[:len(big)] == sorted(big, reverse=True)
+        assert all(r in (2, 3, 4, 5, 7, 11, 13) for r in st[len(big):])
