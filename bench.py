@@ -659,7 +659,7 @@ def main(argv=None, engine=None):
     # where the tensors of barrier()/max_over_ranks() live: on the GPU for RCCL, on the CPU for gloo
     ctl_device = device if (dist is None or backend == "nccl") else None
 
-    api = args.api if args.api != "auto" else ("pipelined" if wl["kind"] == "direct" else "inorder")
+    api = args.api if args.api != "auto" else ("pipelined" if wl["kind"] in ("direct", "pfb") else "inorder")
 
     m = _measure_with_ctl(engine, args.workload, device, ctl_device, seed, args.steps, args.warmup, dist, api,
                           args.min_seconds)
@@ -703,7 +703,7 @@ def main(argv=None, engine=None):
                 if key == args.workload:
                     continue
                 ek = WORKLOADS[key]
-                eapi = "pipelined" if ek["kind"] == "direct" else "inorder"   # only the matrix-core DDC overlaps buffers
+                eapi = "pipelined" if ek["kind"] in ("direct", "pfb") else "inorder"   # the DDC and the PFB overlap buffers
                 e = measure(engine, key, device, seed, steps=500, warmup=50, dist=None, api=eapi, min_seconds=0.5)
                 er = e["r"]
                 extras[key] = dict(workload=ek["name"], msamples_per_s=round(e["value"], 2), api=er["api"],

@@ -815,11 +815,25 @@ int enqueue_pfb_lds(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t st
         h->err = "PFB carry larger than a window";
         return -1;
     }
+    const int *sel = h->mode == GSDR_NOISE ? nullptr : h->d_pfb_sel;
+    const long long wlen = (long long)h->bh.new_0 + h->L;
     hipEvent_t stop = nullptr;
-    if (record_begin(h, st, &stop)) return -1;
-    HIPCHK(h, gsdr::launch_pfb_lds(carry, h->bh.new_0, in, h->d_fft_win, h->d_pfb_tw, h->nfft, h->F, cb,
-                                   h->mode == GSDR_NOISE ? nullptr : h->d_pfb_sel, h->ddc_channels, out, carry_out,
-                                   h->bh.spare_begin, spare_n, (long long)h->bh.new_0 + h->L, st));
+    if (h->pipe_overlap) {
+        // overlapped entry: consecutive buffers run on the compute streams in turn.  What ties them
+        // together is the carry alone: a launch of its own copies this call's leftovers first (it needs
+        // the previous call's carry and this buffer, nothing of this call's frames), its event lets the
+        // next call start, and the frames follow -- beside the frames of the neighbouring buffers.
+        HIPCHK(h, gsdr::launch_pfb_lds(carry, h->bh.new_0, in, h->d_fft_win, h->d_pfb_tw, h->nfft, h->F, 0,
+                                       sel, h->ddc_channels, out, carry_out, h->bh.spare_begin, spare_n, wlen, st));
+        HIPCHK(h, hipEventRecord(h->ev_abs[h->pipe_seq % 4], st));
+        if (record_begin(h, st, &stop)) return -1;
+        HIPCHK(h, gsdr::launch_pfb_lds(carry, h->bh.new_0, in, h->d_fft_win, h->d_pfb_tw, h->nfft, h->F, cb,
+                                       sel, h->ddc_channels, out, nullptr, 0, 0, wlen, st));
+    } else {
+        if (record_begin(h, st, &stop)) return -1;
+        HIPCHK(h, gsdr::launch_pfb_lds(carry, h->bh.new_0, in, h->d_fft_win, h->d_pfb_tw, h->nfft, h->F, cb,
+                                       sel, h->ddc_channels, out, carry_out, h->bh.spare_begin, spare_n, wlen, st));
+    }
     if (stop) HIPCHK(h, hipEventRecord(stop, st));
     h->win_seq++;
     const int ret = h->ddc_channels * cb;  // :546 (TONES), copy_size :638 (NOISE)
@@ -1372,7 +1386,7 @@ static int pipeline_init_parts(gsdr_demod *h) {
 static int pipeline_compute(gsdr_demod *h, gsdr_demod::Slot &sl, hipEvent_t up, const float2 *in, float2 *out) {
     const bool ddc = (h->mode == GSDR_DIRECT && h->decim > 0) ||
                      h->mode == GSDR_TONES || h->mode == GSDR_NOISE;
-    const bool overlap = env_int("GSDR_PIPE_OVERLAP", 1) != 0 && h->mfma && ddc;
+    const bool overlap = env_int("GSDR_PIPE_OVERLAP", 1) != 0 && (h->mfma || h->pfb_lds) && ddc;
     hipStream_t cs = overlap ? h->s_main[h->pipe_seq % (unsigned)h->pipe_streams] : h->stream;
     if (up) HIPCHK(h, hipStreamWaitEvent(cs, up, 0));
     if (overlap) {
