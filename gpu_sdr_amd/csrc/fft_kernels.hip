@@ -202,6 +202,7 @@ struct PfbLdsArgs {
     // instructions; with one or two per butterfly the kernel was bound by them.
     unsigned mag_n, mag_nout;
     unsigned mag_t[16], mag_p[16];     // per stage: t = n / R, p = product of the earlier radices
+    int stage_t[16], stage_tws[16];    // per stage: t and n / (p R), so that no stage divides at run time
     unsigned mag_t4, mag_rt4;          // prime-first stage: t4 = ceil(t / 4), R * t4
 };
 
@@ -215,9 +216,8 @@ __device__ __forceinline__ float2 pfb_window_at(const PfbLdsArgs &a, int q) {
 }
 
 template <int R>
-__device__ __forceinline__ void lds_stage(const float2 *src, float2 *dst, int n, int p, unsigned mag_t, unsigned mag_p,
-                                          const float2 *__restrict__ tw, int FR, int tid) {
-    const int t = n / R, tws = n / (p * R);      // uniform: scalar divisions
+__device__ __forceinline__ void lds_stage(const float2 *src, float2 *dst, int n, int p, int t, int tws, unsigned mag_t,
+                                          unsigned mag_p, const float2 *__restrict__ tw, int FR, int tid) {
     for (int g = tid; g < FR * t; g += 256) {
         const int fr = FR == 1 ? 0 : fdiv(g, mag_t), i = g - fr * t;
         const int k = i - fdiv(i, mag_p) * p;
@@ -247,8 +247,8 @@ __device__ __forceinline__ void lds_stage(const float2 *src, float2 *dst, int n,
 // of the plain sum (which cost 11 of the 27 us of a 1230 = 41*2*3*5-point buffer).  One q and four
 // consecutive columns i per work item; roots: w_R^m = (cos, -sin)(2 pi m / R), m < R, in the LDS.
 __device__ __forceinline__ void lds_stage_prime_first(int R, float2 *src, float2 *dst, int n, const float2 *roots,
-                                                      unsigned mag_t, unsigned mag_t4, unsigned mag_rt4, int FR, int tid) {
-    const int t = n / R, t4 = (t + 3) >> 2, h = (R - 1) >> 1;
+                                                      int t, unsigned mag_t, unsigned mag_t4, unsigned mag_rt4, int FR, int tid) {
+    const int t4 = (t + 3) >> 2, h = (R - 1) >> 1;
     // pass 1: S and D in place
     for (int g = tid; g < FR * h * t; g += 256) {
         const int rr = fdiv(g, mag_t), i = g - rr * t;          // rr = fr * h + (r - 1)
@@ -359,6 +359,7 @@ __global__ __launch_bounds__(256) GSDR_NO_PK void pfb_lds_kernel(const PfbLdsArg
     // the parameters of stage s live in lane s of three registers
     const int st_lane = tid & 15;
     const int st_radix = a.radices[st_lane], st_mag_t = (int)a.mag_t[st_lane], st_mag_p = (int)a.mag_p[st_lane];
+    const int st_t = a.stage_t[st_lane], st_tws = a.stage_tws[st_lane];
     // the bins of the first output columns of this thread: loaded now, used behind the last stage
     int sel0[4];
 #pragma unroll
@@ -429,17 +430,18 @@ __global__ __launch_bounds__(256) GSDR_NO_PK void pfb_lds_kernel(const PfbLdsArg
         // (a.radices[s] with a running s is a scalar load and its latency in every stage)
         const int R = __builtin_amdgcn_readlane(st_radix, s);
         const unsigned mt = (unsigned)__builtin_amdgcn_readlane(st_mag_t, s), mp = (unsigned)__builtin_amdgcn_readlane(st_mag_p, s);
+        const int st = __builtin_amdgcn_readlane(st_t, s), stw = __builtin_amdgcn_readlane(st_tws, s);
         switch (R) {
-            case 2: lds_stage<2>(src, dst, n, p, mt, mp, tw, FR, tid); break;
-            case 3: lds_stage<3>(src, dst, n, p, mt, mp, tw, FR, tid); break;
-            case 4: lds_stage<4>(src, dst, n, p, mt, mp, tw, FR, tid); break;
-            case 5: lds_stage<5>(src, dst, n, p, mt, mp, tw, FR, tid); break;
-            case 7: lds_stage<7>(src, dst, n, p, mt, mp, tw, FR, tid); break;
-            case 11: lds_stage<11>(src, dst, n, p, mt, mp, tw, FR, tid); break;
-            case 13: lds_stage<13>(src, dst, n, p, mt, mp, tw, FR, tid); break;
+            case 2: lds_stage<2>(src, dst, n, p, st, stw, mt, mp, tw, FR, tid); break;
+            case 3: lds_stage<3>(src, dst, n, p, st, stw, mt, mp, tw, FR, tid); break;
+            case 4: lds_stage<4>(src, dst, n, p, st, stw, mt, mp, tw, FR, tid); break;
+            case 5: lds_stage<5>(src, dst, n, p, st, stw, mt, mp, tw, FR, tid); break;
+            case 7: lds_stage<7>(src, dst, n, p, st, stw, mt, mp, tw, FR, tid); break;
+            case 11: lds_stage<11>(src, dst, n, p, st, stw, mt, mp, tw, FR, tid); break;
+            case 13: lds_stage<13>(src, dst, n, p, st, stw, mt, mp, tw, FR, tid); break;
             default:
                 if (s == 0)
-                    lds_stage_prime_first(R, src, dst, n, roots, mt, a.mag_t4, a.mag_rt4, FR, tid);
+                    lds_stage_prime_first(R, src, dst, n, roots, st, mt, a.mag_t4, a.mag_rt4, FR, tid);
                 else
                     lds_stage_generic(R, src, dst, n, p, tw, FR, tid);
                 break;
@@ -717,6 +719,8 @@ hipError_t launch_pfb_lds(const float2 *carry, int new_0, const float2 *in, cons
         for (int s = 0; s < a.n_radices; ++s) {
             a.mag_t[s] = magic(nfft / a.radices[s]);
             a.mag_p[s] = magic(p);
+            a.stage_t[s] = nfft / a.radices[s];
+            a.stage_tws[s] = nfft / (p * a.radices[s]);
             p *= a.radices[s];
         }
         if (a.n_radices > 0 && a.radices[0] > 13) {
