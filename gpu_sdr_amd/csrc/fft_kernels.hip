@@ -217,8 +217,8 @@ __device__ __forceinline__ float2 pfb_window_at(const PfbLdsArgs &a, int q) {
 
 template <int R>
 __device__ __forceinline__ void lds_stage(const float2 *src, float2 *dst, int n, int p, int t, int tws, unsigned mag_t,
-                                          unsigned mag_p, const float2 *__restrict__ tw, int FR, int tid) {
-    for (int g = tid; g < FR * t; g += 256) {
+                                          unsigned mag_p, const float2 *__restrict__ tw, int FR, int tid, int NT) {
+    for (int g = tid; g < FR * t; g += NT) {
         const int fr = FR == 1 ? 0 : fdiv(g, mag_t), i = g - fr * t;
         const int k = i - fdiv(i, mag_p) * p;
         const int j = (i - k) * R + k;
@@ -247,10 +247,10 @@ __device__ __forceinline__ void lds_stage(const float2 *src, float2 *dst, int n,
 // of the plain sum (which cost 11 of the 27 us of a 1230 = 41*2*3*5-point buffer).  One q and four
 // consecutive columns i per work item; roots: w_R^m = (cos, -sin)(2 pi m / R), m < R, in the LDS.
 __device__ __forceinline__ void lds_stage_prime_first(int R, float2 *src, float2 *dst, int n, const float2 *roots,
-                                                      int t, unsigned mag_t, unsigned mag_t4, unsigned mag_rt4, int FR, int tid) {
+                                                      int t, unsigned mag_t, unsigned mag_t4, unsigned mag_rt4, int FR, int tid, int NT) {
     const int t4 = (t + 3) >> 2, h = (R - 1) >> 1;
     // pass 1: S and D in place
-    for (int g = tid; g < FR * h * t; g += 256) {
+    for (int g = tid; g < FR * h * t; g += NT) {
         const int rr = fdiv(g, mag_t), i = g - rr * t;          // rr = fr * h + (r - 1)
         const int fr = FR == 1 ? 0 : rr / h, r = rr - fr * h + 1;
         const int lo = fr * n + i + r * t, hi = fr * n + i + (R - r) * t;
@@ -262,7 +262,7 @@ __device__ __forceinline__ void lds_stage_prime_first(int R, float2 *src, float2
     // pass 2: q = 0 .. h; work item = (frame, q, group of four columns)
     const int items = (h + 1) * t4;
     (void)mag_rt4;
-    for (int g = tid; g < FR * items; g += 256) {
+    for (int g = tid; g < FR * items; g += NT) {
         const int fr = FR == 1 ? 0 : g / items, rem = g - fr * items;
         const int q = fdiv(rem, mag_t4), i0 = (rem - q * t4) << 2;
         int off[4];
@@ -304,9 +304,9 @@ __device__ __forceinline__ void lds_stage_prime_first(int R, float2 *src, float2
 // any further prime radix above 13 (two large prime factors in one length: rare): one output per work
 // item, out[q] = sum_r x[i + r t] w_n^(r (k tws + q n/R)), roots from the twiddle table
 __device__ __forceinline__ void lds_stage_generic(int R, const float2 *src, float2 *dst, int n, int p,
-                                                  const float2 *__restrict__ tw, int FR, int tid) {
+                                                  const float2 *__restrict__ tw, int FR, int tid, int NT) {
     const int t = n / R, tws = n / (p * R), nr = n / R;
-    for (int g = tid; g < FR * t * R; g += 256) {
+    for (int g = tid; g < FR * t * R; g += NT) {
         const int fr = g / (t * R), rem = g - fr * (t * R);
         const int q = rem / t, i = rem - q * t;
         const int k = i % p;
@@ -327,9 +327,11 @@ __device__ __forceinline__ void lds_stage_generic(int R, const float2 *src, floa
 }
 
 // TWL: the twiddle table w_n^k is copied into the LDS first (frames of up to kPfbLdsTwMaxN points); the
-// stages then find their factors at LDS latency instead of one L1 round trip per stage
-template <bool TWL>
-__global__ __launch_bounds__(256) GSDR_NO_PK void pfb_lds_kernel(const PfbLdsArgs a) {
+// stages then find their factors at LDS latency instead of one L1 round trip per stage.
+// NT: threads per workgroup -- 256, or 512 (1024 would cap a thread at 128 registers: spills) for frames of 2048 points and more (a buffer has few of them:
+// the frame's own parallelism has to fill the compute unit)
+template <bool TWL, int NT>
+__global__ __launch_bounds__(NT) GSDR_NO_PK void pfb_lds_kernel(const PfbLdsArgs a) {
     extern __shared__ float2 pfb_lds[];
     const int tid = threadIdx.x, n = a.n, FR = a.FR;
     // Workgroups are dealt to the 8 XCDs in turn (blockIdx % 8) and each XCD has its own L2.  Frame r
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(256) GSDR_NO_PK void pfb_lds_kernel(const PfbLdsArg
     if (blockIdx.x >= padded) {
         // leftovers of this call -> carry of the next one
         const int j0 = (int)(blockIdx.x - padded) * 2048;
-        for (int j = j0 + tid; j < j0 + 2048 && j < a.spare_n; j += 256)
+        for (int j = j0 + tid; j < j0 + 2048 && j < a.spare_n; j += NT)
             a.carry_out[j] = pfb_window_at(a, a.spare_begin + j);
         return;
     }
@@ -364,7 +366,7 @@ __global__ __launch_bounds__(256) GSDR_NO_PK void pfb_lds_kernel(const PfbLdsArg
     int sel0[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const int idx = tid + 256 * c;
+        const int idx = tid + NT * c;
         const int fr = FR == 1 ? 0 : fdiv(idx, a.mag_nout);
         const int u = idx - fr * a.n_out;
         sel0[c] = a.sel && idx < FR * a.n_out ? a.sel[u] : u;
@@ -372,13 +374,13 @@ __global__ __launch_bounds__(256) GSDR_NO_PK void pfb_lds_kernel(const PfbLdsArg
     bool first = true;
     const bool all_in = f0 * n >= a.new_0 && a.frames_n - f0 >= FR;     // uniform; q >= new_0 for every read then
     const float2 *in_base = a.in - a.new_0;
-    for (int base = tid; base < FR * n; base += 1024) {
+    for (int base = tid; base < FR * n; base += 4 * NT) {
         int kk[4], q0[4];
         bool ok[4];
         float2 acc[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const int idx = base + 256 * c;
+            const int idx = base + NT * c;
             const int idc = idx < FR * n ? idx : FR * n - 1;
             const int fr = FR == 1 ? 0 : fdiv(idc, a.mag_n);
             kk[c] = idc - fr * n;
@@ -404,8 +406,8 @@ __global__ __launch_bounds__(256) GSDR_NO_PK void pfb_lds_kernel(const PfbLdsArg
             if (first) {
                 first = false;
                 if (TWL)
-                    for (int k = tid; k < n; k += 256) twl[k] = a.tw[k];
-                for (int m = tid; m < R0; m += 256) roots[m] = a.tw[m * (n / R0)];
+                    for (int k = tid; k < n; k += NT) twl[k] = a.tw[k];
+                for (int m = tid; m < R0; m += NT) roots[m] = a.tw[m * (n / R0)];
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(256) GSDR_NO_PK void pfb_lds_kernel(const PfbLdsArg
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-            if (base + 256 * c < FR * n) A[base + 256 * c] = ok[c] ? acc[c] : mk2(0.f, 0.f);
+            if (base + NT * c < FR * n) A[base + NT * c] = ok[c] ? acc[c] : mk2(0.f, 0.f);
     }
     __syncthreads();
     fft_stamp(1);
@@ -432,18 +434,18 @@ __global__ __launch_bounds__(256) GSDR_NO_PK void pfb_lds_kernel(const PfbLdsArg
         const unsigned mt = (unsigned)__builtin_amdgcn_readlane(st_mag_t, s), mp = (unsigned)__builtin_amdgcn_readlane(st_mag_p, s);
         const int st = __builtin_amdgcn_readlane(st_t, s), stw = __builtin_amdgcn_readlane(st_tws, s);
         switch (R) {
-            case 2: lds_stage<2>(src, dst, n, p, st, stw, mt, mp, tw, FR, tid); break;
-            case 3: lds_stage<3>(src, dst, n, p, st, stw, mt, mp, tw, FR, tid); break;
-            case 4: lds_stage<4>(src, dst, n, p, st, stw, mt, mp, tw, FR, tid); break;
-            case 5: lds_stage<5>(src, dst, n, p, st, stw, mt, mp, tw, FR, tid); break;
-            case 7: lds_stage<7>(src, dst, n, p, st, stw, mt, mp, tw, FR, tid); break;
-            case 11: lds_stage<11>(src, dst, n, p, st, stw, mt, mp, tw, FR, tid); break;
-            case 13: lds_stage<13>(src, dst, n, p, st, stw, mt, mp, tw, FR, tid); break;
+            case 2: lds_stage<2>(src, dst, n, p, st, stw, mt, mp, tw, FR, tid, NT); break;
+            case 3: lds_stage<3>(src, dst, n, p, st, stw, mt, mp, tw, FR, tid, NT); break;
+            case 4: lds_stage<4>(src, dst, n, p, st, stw, mt, mp, tw, FR, tid, NT); break;
+            case 5: lds_stage<5>(src, dst, n, p, st, stw, mt, mp, tw, FR, tid, NT); break;
+            case 7: lds_stage<7>(src, dst, n, p, st, stw, mt, mp, tw, FR, tid, NT); break;
+            case 11: lds_stage<11>(src, dst, n, p, st, stw, mt, mp, tw, FR, tid, NT); break;
+            case 13: lds_stage<13>(src, dst, n, p, st, stw, mt, mp, tw, FR, tid, NT); break;
             default:
                 if (s == 0)
-                    lds_stage_prime_first(R, src, dst, n, roots, st, mt, a.mag_t4, a.mag_rt4, FR, tid);
+                    lds_stage_prime_first(R, src, dst, n, roots, st, mt, a.mag_t4, a.mag_rt4, FR, tid, NT);
                 else
-                    lds_stage_generic(R, src, dst, n, p, tw, FR, tid);
+                    lds_stage_generic(R, src, dst, n, p, tw, FR, tid, NT);
                 break;
         }
         __syncthreads();
@@ -455,11 +457,11 @@ __global__ __launch_bounds__(256) GSDR_NO_PK void pfb_lds_kernel(const PfbLdsArg
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const int idx = tid + 256 * c;
+        const int idx = tid + NT * c;
         const int fr = FR == 1 ? 0 : fdiv(idx, a.mag_nout), u = idx - fr * a.n_out;
         if (idx < FR * a.n_out && f0 + fr < a.frames_n) a.out[(size_t)(f0 + fr) * a.n_out + u] = src[fr * n + sel0[c]];
     }
-    for (int idx = tid + 1024; idx < FR * a.n_out; idx += 256) {
+    for (int idx = tid + 4 * NT; idx < FR * a.n_out; idx += NT) {
         const int fr = FR == 1 ? 0 : fdiv(idx, a.mag_nout), u = idx - fr * a.n_out;
         const int r = f0 + fr;
         if (r < a.frames_n) a.out[(size_t)r * a.n_out + u] = src[fr * n + (a.sel ? a.sel[u] : u)];
@@ -739,21 +741,24 @@ hipError_t launch_pfb_lds(const float2 *carry, int new_0, const float2 *in, cons
     static std::atomic<unsigned long long> attr_done{0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return hipErrorInvalidDevice;
+    const bool wide = nfft >= 2048;                      // 512 threads per frame
+    const void *fn = twl ? (wide ? reinterpret_cast<const void *>(pfb_lds_kernel<true, 512>)
+                                 : reinterpret_cast<const void *>(pfb_lds_kernel<true, 256>))
+                         : (wide ? reinterpret_cast<const void *>(pfb_lds_kernel<false, 512>)
+                                 : reinterpret_cast<const void *>(pfb_lds_kernel<false, 256>));
     if (!(attr_done.load() >> dev & 1ULL)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(pfb_lds_kernel<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, kPfbLdsMaxBytes);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(pfb_lds_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, kPfbLdsMaxBytes);
-        if (e != hipSuccess) return e;
+        for (const void *f : {reinterpret_cast<const void *>(pfb_lds_kernel<true, 256>),
+                              reinterpret_cast<const void *>(pfb_lds_kernel<true, 512>),
+                              reinterpret_cast<const void *>(pfb_lds_kernel<false, 256>),
+                              reinterpret_cast<const void *>(pfb_lds_kernel<false, 512>)}) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kPfbLdsMaxBytes);
+            if (e != hipSuccess) return e;
+        }
         attr_done.fetch_or(1ULL << dev);
     }
     if (lds > (size_t)kPfbLdsMaxBytes) return hipErrorInvalidValue;
-    if (twl)
-        hipLaunchKernelGGL(pfb_lds_kernel<true>, dim3(grid), dim3(256), lds, st, a);
-    else
-        hipLaunchKernelGGL(pfb_lds_kernel<false>, dim3(grid), dim3(256), lds, st, a);
-    return hipGetLastError();
+    void *kargs[] = {&a};
+    return hipLaunchKernel(fn, dim3(grid), dim3(wide ? 512 : 256), kargs, lds, st);
 }
 
 const char *pfb_lds_kernel_name() { return "pfb_lds_kernel"; }
