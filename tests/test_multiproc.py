@@ -198,3 +198,29 @@ def test_backend_choice():
     finally:
         if old is not None:
             os.environ["GSDR_BENCH_BACKEND"] = old
+
+
+def test_rooflines_of_the_hbm_bound_paths():
+    """bench.rooflines(): TONES through the frame-per-workgroup kernel is priced against HBM (algorithmic
+    bytes: one read of the samples + the selected bins), not against a matrix or vector pipe; a chirp
+    launch shorter than an event pair is priced with the step period of the event-free region."""
+    import bench
+    wl = bench.WORKLOADS["pfb"]
+    r = dict(kernel="pfb_lds_kernel", kernel_ms=20.0e-3 * 100, kernel_launches=100, n_tones=1024, api="inorder")
+    roof, roof_hbm = bench.rooflines(wl, r, "pfb")
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == bench.HBM_PEAK_GBS
+    ab = 8.0 * (1.0 + 1024 / 1230) * bench.L
+    assert abs(roof["algorithmic_bytes_per_launch"] - ab) < 1.0
+    assert abs(roof["achieved"] - ab / 20.0e-6 / 1e9) < 0.5 and abs(roof["frac"] - roof["achieved"] / 8000.0) < 1e-4
+    # the same workload on the DDC kernels stays an MFMA roofline with both flop counts
+    r2 = dict(r, kernel="ddc_mfma_ring16p_kernel")
+    roof2, _ = bench.rooflines(wl, r2, "pfb")
+    assert roof2["bound"] == "mfma" and roof2["executed_mfma_flops_per_launch"] == round(24.0 * 4 * 1024 * bench.L)
+    assert roof2["algorithmic_flops_per_launch"] == round(1024 * (6 + 4 * 4) * bench.L)
+    # chirp: events say 7 us, back-to-back launches 4 us per step
+    c4 = bench.WORKLOADS["c4"]
+    rc = dict(kernel="chirp_lockin_kernel", kernel_ms=7.0e-3 * 50, kernel_launches=50, n_tones=1, api="inorder")
+    roof3, _ = bench.rooflines(c4, rc, "c4", period_s=4.0e-6)
+    assert roof3["kernel_us"] == 4.0 and roof3["kernel_us_between_events"] == 7.0 and "step period" in roof3["measured_with"]
+    roof4, _ = bench.rooflines(c4, rc, "c4", period_s=9.0e-6)      # a period longer than the events say: keep the events
+    assert roof4["kernel_us"] == 7.0 and "kernel_us_between_events" not in roof4
