@@ -131,6 +131,7 @@ struct gsdr_demod {
     std::vector<hipStream_t> dirty;
     hipEvent_t ev_join = nullptr;
     bool pipe_overlap = false;         // set around the compute of an overlapped call
+    bool pipe_overlap_allowed = true;  // GSDR_PIPE_OVERLAP, read when the pipeline is created
     unsigned long long pipe_seq = 0;   // overlapped calls so far
     unsigned long long call_no = 0;    // absmax slot rotation
     // ---- TONES ----
@@ -1362,6 +1363,7 @@ static int pipeline_init_parts(gsdr_demod *h) {
         HIPCHK(h, hipStreamCreateWithPriority(&h->s_main[i], hipStreamNonBlocking, prio_least));
     }
     h->pipe_streams = env_int("GSDR_PIPE_STREAMS", kPipeStreams);
+    h->pipe_overlap_allowed = env_int("GSDR_PIPE_OVERLAP", 1) != 0;
     if (h->pipe_streams < 1 || h->pipe_streams > kPipeStreams) h->pipe_streams = kPipeStreams;
     for (int i = 0; i < 4; ++i) HIPCHK(h, hipEventCreateWithFlags(&h->ev_abs[i], hipEventDisableTiming));
     return 0;
@@ -1386,7 +1388,7 @@ static int pipeline_init_parts(gsdr_demod *h) {
 static int pipeline_compute(gsdr_demod *h, gsdr_demod::Slot &sl, hipEvent_t up, const float2 *in, float2 *out) {
     const bool ddc = (h->mode == GSDR_DIRECT && h->decim > 0) ||
                      h->mode == GSDR_TONES || h->mode == GSDR_NOISE;
-    const bool overlap = env_int("GSDR_PIPE_OVERLAP", 1) != 0 && (h->mfma || h->pfb_lds) && ddc;
+    const bool overlap = h->pipe_overlap_allowed && (h->mfma || h->pfb_lds) && ddc;
     hipStream_t cs = overlap ? h->s_main[h->pipe_seq % (unsigned)h->pipe_streams] : h->stream;
     if (up) HIPCHK(h, hipStreamWaitEvent(cs, up, 0));
     if (overlap) {

@@ -626,6 +626,8 @@ NOISE_FFT_CASES = [
     (17 * 19 * 4, 3, 30_000, 3),               # 1292: two primes above 13 (19 first, 17 through the generic stage)
     (48, 8, 300, 6),                           # frames longer than a buffer: calls without a frame; 22 frames per workgroup
     (131 * 4, 2, 20_000, 2),                   # 524: prime factor 131 > 127 -> not for the in-LDS kernel
+    (101, 2, 5_000, 3),                        # a prime frame: one stage, one column per frame, 11 frames per workgroup
+    (2 * 17, 3, 3_000, 3),                     # 34: 31 frames per workgroup, prime-first stage with two columns
 ]
 
 
