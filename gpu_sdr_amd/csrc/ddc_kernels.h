@@ -139,6 +139,8 @@ hipError_t fft_forward(const FftPlan &pl, float2 *src, float2 *dst, float2 *tmp,
 // frames[r][k] = sum_{i<avg} raw[(r+i)*nfft + k] * window[i*nfft + k], r < frames_n (ref: cpp/kernels.cu:474-516)
 hipError_t launch_pfb_filter(const float2 *raw, const float *window, int nfft, int avg, int frames_n, float2 *frames,
                              hipStream_t st);
+// out[frame][u] = spectra[frame][sel[u]], u < n_out (ref: tone_select, cpp/kernels.cu:520-554)
+hipError_t launch_pfb_select(const float2 *spectra, int nfft, int frames_n, const int *sel, int n_out, float2 *out, hipStream_t st);
 const char *fft_kernel_name();
 // The whole PFB of a frame in one workgroup (filter, in-LDS transform, bin selection): frames of up to
 // kPfbLdsMaxN points whose prime factors do not exceed kPfbLdsMaxPrime.

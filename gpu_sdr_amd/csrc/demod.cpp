@@ -148,6 +148,7 @@ struct gsdr_demod {
     bool noise_fft = false;
     gsdr::FftPlan fft{};
     float2 *d_fft_a = nullptr, *d_fft_b = nullptr;   // frames / scratch, batching * max(nfft, m) each
+    float2 *d_fft_c = nullptr;                       // TONES through these stages: the spectra the bins are picked from
     float *d_fft_win = nullptr;                      // the PFB window on the device
     // ---- the parameters this handle was created with (gsdr_demod_prepare's rehearsal builds a twin) ----
     gsdr_param_c pc{};
@@ -792,14 +793,19 @@ int enqueue_noise_fft(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t 
         hipEvent_t stop = nullptr;
         if (record_begin(h, st, &stop)) return -1;
         HIPCHK(h, gsdr::launch_pfb_filter(win, h->d_fft_win, h->nfft, h->F, cb, h->d_fft_a, st));   // :580
-        HIPCHK(h, gsdr::fft_forward(h->fft, h->d_fft_a, out, h->d_fft_b, cb, st));                   // :583
+        if (h->d_fft_c) {                                                                            // TONES: :531-540
+            HIPCHK(h, gsdr::fft_forward(h->fft, h->d_fft_a, h->d_fft_c, h->d_fft_b, cb, st));
+            HIPCHK(h, gsdr::launch_pfb_select(h->d_fft_c, h->nfft, cb, h->d_pfb_sel, h->ddc_channels, out, st));
+        } else {
+            HIPCHK(h, gsdr::fft_forward(h->fft, h->d_fft_a, out, h->d_fft_b, cb, st));               // :583
+        }
         if (stop) HIPCHK(h, hipEventRecord(stop, st));
     }
     h->prev_spare_begin = h->bh.spare_begin;
     h->prev_spare_samples = h->bh.spare_samples > 0 ? h->bh.spare_samples : 0;
     h->win_seq++;
-    const int ret = h->nfft * cb;        // copy_size :638
-    gsdr_buffer_helper_update(&h->bh);   // :644
+    const int ret = h->ddc_channels * cb;   // :546 (TONES), copy_size :638 (NOISE: every bin)
+    gsdr_buffer_helper_update(&h->bh);      // :552 / :644
     return ret;
 }
 
@@ -1144,11 +1150,22 @@ gsdr_demod *gsdr_demod_create(const gsdr_param_c *p) {
                 h->capacity = (long long)n_ch * h->batching;               // :147 / :288
                 break;
             }
-            if (noise_fft) {
+            // frames the LDS kernel does not take: the polyphase filter and one launch per radix stage through
+            // memory (§4.5) -- NOISE keeps every bin, TONES picks its bins out of a scratch spectrum.  For
+            // TONES this replaces one DDC per bin when the frame is long (above 8192 points a frame is a
+            // window of 32 768+ samples: the DDC rows become thousand-block loops on a handful of workgroups)
+            const bool tones_global = !noise && env_int("GSDR_TONES_FFT", 1) != 0 && h->nfft > gsdr::kPfbLdsMaxN;
+            if (noise_fft || tones_global) {
                 h->noise_fft = true;
                 h->F = F;
                 h->M = h->nfft;
                 h->kernel_name = gsdr::fft_kernel_name();
+                if (tones_global) {
+                    std::vector<int> sel(tone.begin(), tone.end());
+                    if (!need(upload(&h->d_pfb_sel, sel) == hipSuccess &&
+                                  dev_alloc(&h->d_fft_c, (size_t)h->nfft * (size_t)h->batching) == hipSuccess,
+                              "TONES allocation failed")) return nullptr;
+                }
                 if (!need(gsdr::fft_plan_build(h->fft, h->nfft) == 0, "cannot plan an FFT of fft_tones points")) return nullptr;
                 const size_t len = (size_t)(h->fft.m > h->nfft ? h->fft.m : h->nfft) * (size_t)h->batching;
                 const size_t nwin = (size_t)h->nfft * h->batching * 2;
@@ -1584,6 +1601,7 @@ void gsdr_demod_close(gsdr_demod *h) {
     gsdr::fft_plan_free(h->fft);
     if (h->d_fft_a) (void)hipFree(h->d_fft_a);
     if (h->d_fft_b) (void)hipFree(h->d_fft_b);
+    if (h->d_fft_c) (void)hipFree(h->d_fft_c);
     if (h->d_fft_win) (void)hipFree(h->d_fft_win);
     if (h->d_pfb_tw) (void)hipFree(h->d_pfb_tw);
     if (h->d_pfb_sel) (void)hipFree(h->d_pfb_sel);

@@ -657,6 +657,23 @@ hipError_t fft_forward(const FftPlan &pl, float2 *src, float2 *dst, float2 *tmp,
     return e;
 }
 
+// ref: tone_select, cpp/kernels.cu:520-554 -- out[frame][u] = spectra[frame][bin(u)]
+__global__ __launch_bounds__(256) GSDR_NO_PK void pfb_select_kernel(const float2 *__restrict__ spectra, int n, const int *__restrict__ sel,
+                                                         int n_out, long long total, float2 *__restrict__ out) {
+    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= total) return;
+    const long long r = g / n_out;
+    const int u = (int)(g - r * n_out);
+    out[g] = spectra[(size_t)r * n + sel[u]];
+}
+
+hipError_t launch_pfb_select(const float2 *spectra, int nfft, int frames_n, const int *sel, int n_out, float2 *out, hipStream_t st) {
+    if (nfft < 1 || frames_n < 1 || n_out < 1 || !spectra || !sel || !out) return hipErrorInvalidValue;
+    const long long total = (long long)frames_n * n_out;
+    hipLaunchKernelGGL(pfb_select_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, spectra, nfft, sel, n_out, total, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_pfb_filter(const float2 *raw, const float *window, int nfft, int avg, int frames_n, float2 *frames,
                              hipStream_t st) {
     if (nfft < 1 || avg < 1 || frames_n < 1 || !raw || !window || !frames) return hipErrorInvalidValue;

@@ -11,7 +11,7 @@ L, rate = 1_000_000, 200_000_000
 x = [(torch.randn(L, device=dev) + 1j * torch.randn(L, device=dev)).to(torch.complex64) for _ in range(4)]
 SIZES = [int(v) for v in sys.argv[1:]] or [64, 256, 1000, 1024, 1200, 1230, 1250, 2048, 17 * 64, 41 * 32, 127 * 8, 4096, 8192]
 for nfft in SIZES:
-    for mode in (("NOISE",) if nfft > 8192 else ("TONES",)) if len(sys.argv) > 1 else ("TONES", "NOISE"):
+    for mode in ("TONES", "NOISE"):
         N = min(1024, nfft)
         rng = np.random.default_rng(nfft)
         freq = [int(f) for f in rng.choice(np.arange(-rate // 2 + 1, rate // 2), size=N, replace=False)]

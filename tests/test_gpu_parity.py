@@ -631,6 +631,37 @@ NOISE_FFT_CASES = [
 ]
 
 
+@pytest.mark.parametrize("path", ["fft", "ddc"])
+@pytest.mark.parametrize("nfft,avg,L,nbuf", [(16384, 4, 300_000, 3), (12_000, 2, 100_000, 4)], ids=lambda v: str(v))
+def test_tones_long_frames(cuda_device, gsdr_lib, oracle_mod, monkeypatch, nfft, avg, L, nbuf, path):
+    """TONES with frames above 8192 points (the in-LDS kernel's limit): the polyphase filter, the
+    FFT stages through memory and a bin selection ("fft", the library's choice) against one DDC per
+    bin on the matrix cores (GSDR_TONES_FFT=0), both against the oracle."""
+    if path == "ddc":
+        monkeypatch.setenv("GSDR_TONES_FFT", "0")
+    rate, N = 200_000_000, 24
+    rng = np.random.default_rng(nfft)
+    freq = rng.choice(np.arange(-rate // 2 + 1, rate // 2), size=N, replace=False)
+    dem = make_pfb(freq, rate, nfft, avg, L)
+    assert dem.kernel_name == "fft_pass_kernel" if path == "fft" else dem.kernel_name.startswith("ddc_")
+    ref = oracle_mod.Pfb(freq, rate, nfft, avg, L)
+    np.testing.assert_array_equal(dem.bins(), ref.bins())
+    assert dem.out_capacity == N * ref.batching
+    emitted = 0
+    for c in range(nbuf):
+        x = crandn(rng, L)
+        y = (run_host if c % 2 else run_device)(dem, x, *(() if c % 2 else (cuda_device,)))
+        yr = ref.process(x)
+        assert y.size == yr.size, (c, y.size, yr.size)
+        if yr.size:
+            emitted += 1
+            e = float(np.linalg.norm(y.reshape(-1, N) - yr.reshape(-1, N)) / np.linalg.norm(yr))
+            record_margin(e, "all tones together")
+            assert e <= TOL
+    assert emitted >= 2
+    dem.close()
+
+
 def pfb_lds_fits(nfft):
     """lengths the frame-per-workgroup kernel takes: <= 8192 points, no prime factor above 127"""
     m, q, largest = nfft, 2, 1
