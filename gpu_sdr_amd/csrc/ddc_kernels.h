@@ -55,7 +55,7 @@ hipError_t launch_mix(int K, const DdcLaunch &a, hipStream_t st);
 hipError_t launch_ddc_flat_main(int F, int PK, const DdcLaunch &a, hipStream_t st);
 const char *ddc_kernel_name();
 const char *ddc_flat_kernel_name();
-const char *mix_kernel_name();
+const char *mix_kernel_name(int n_tones);   // at most 32 tones: several sample phases per wave
 
 // ---- DDC on the matrix cores (ddc_mfma.hip) --------------------------------
 struct MfmaShape {

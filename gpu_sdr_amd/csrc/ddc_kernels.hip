@@ -249,6 +249,63 @@ __global__ __launch_bounds__(256) void mix_kernel(
     }
 }
 
+// The same for at most 32 tones: with a lane per tone a wave of mix_kernel has 64 - N idle lanes and
+// writes N * 8 bytes per store (8 tones: 42 us per 1 M-sample buffer, 0.21 of the HBM peak).  Here a
+// wave takes T = 2^tshift >= N tones x S = 64 / T consecutive samples at a time: lane = (sample phase
+// sub, tone n), the lane's samples of a K-sample unit are lo = sub, sub + S, ...; one store covers
+// S consecutive samples x T tones -- 512 contiguous bytes when T == N.  Same tables, same arithmetic per
+// element (bit-identical to mix_kernel).
+template <int K>
+__global__ __launch_bounds__(256) void mix_small_kernel(
+    const float2 *__restrict__ x, const float2 *__restrict__ btab,
+    const double2 *__restrict__ wk, const unsigned *__restrict__ fmod,
+    float2 *__restrict__ out, DdcShape sh, int tshift) {
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int chunk = (int)blockIdx.x * 4 + wid;
+    if (chunk >= sh.nch) return;
+    const int S = 64 >> tshift;                  // sample phases per wave, S <= K
+    const int n = lane & ((1 << tshift) - 1), sub = lane >> tshift;
+    const int N = sh.N, Npad = sh.Npad;
+
+    float2 B[K / 2];                             // S >= 2: at most K / 2 samples per lane and unit
+#pragma unroll
+    for (int m = 0; m < K / 2; ++m) {
+        const int lo = sub + S * m;
+        B[m] = btab[(size_t)(lo < K ? lo : 0) * Npad + n];
+    }
+    const double2 WK = wk[n];
+    const long long u0 = chunk_begin(chunk, sh);
+    const long long u1 = chunk_begin(chunk + 1, sh);
+    const long long total = sh.total;  // L
+    const unsigned long long s0 =
+        mod_rate(sh.idx0 + (unsigned long long)u0 * sh.m_mod_rate, sh.rate, sh.rate_magic);
+    const unsigned long long ph = mod_rate((unsigned long long)fmod[n] * s0, sh.rate, sh.rate_magic);
+    double Pr, Pi;
+    exact_phasor(ph, sh.inv_rate, Pr, Pi);
+
+    for (long long u = u0; u < u1; ++u) {
+        const long long base = u * K;
+        const float pr = (float)Pr, pi = (float)Pi;
+#pragma unroll
+        for (int m = 0; m < K / 2; ++m) {
+            const int lo = sub + S * m;
+            if (lo < K && base + lo < total) {
+                const float2 xs = x[base + lo];
+                const float ur = xs.x * B[m].x - xs.y * B[m].y;
+                const float ui = xs.x * B[m].y + xs.y * B[m].x;
+                float2 o;
+                o.x = pr * ur - pi * ui;
+                o.y = pr * ui + pi * ur;
+                if (n < N) out[(size_t)(base + lo) * N + n] = o;
+            }
+        }
+        const double t = Pr * WK.x - Pi * WK.y;
+        Pi = Pr * WK.y + Pi * WK.x;
+        Pr = t;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
@@ -302,6 +359,18 @@ hipError_t launch_ddc(int F, int K, const DdcLaunch &a, hipStream_t st, hipEvent
 }
 
 hipError_t launch_mix(int K, const DdcLaunch &a, hipStream_t st) {
+    if (a.sh.N <= 32 && a.sh.TW == 1 && (K == 16 || K == 32)) {
+        // few tones: several sample phases per wave (mix_small_kernel); T >= 2 keeps S = 64 / T <= K / ... <= 32
+        int tshift = 1;
+        while ((1 << tshift) < a.sh.N) ++tshift;
+        if ((64 >> tshift) > K) tshift = K == 16 ? 2 : 1;
+        const int grid = (a.sh.nch + 3) / 4;
+        if (K == 16)
+            hipLaunchKernelGGL((mix_small_kernel<16>), dim3(grid), dim3(256), 0, st, a.x, a.btab, a.wk, a.fmod, a.out, a.sh, tshift);
+        else
+            hipLaunchKernelGGL((mix_small_kernel<32>), dim3(grid), dim3(256), 0, st, a.x, a.btab, a.wk, a.fmod, a.out, a.sh, tshift);
+        return hipGetLastError();
+    }
     const int waves = a.sh.TW * a.sh.nch;
     const int grid = (waves + 3) / 4;
     if (K == 16)
@@ -316,6 +385,6 @@ hipError_t launch_mix(int K, const DdcLaunch &a, hipStream_t st) {
 }
 
 const char *ddc_kernel_name() { return "ddc_kernel"; }
-const char *mix_kernel_name() { return "mix_kernel"; }
+const char *mix_kernel_name(int n_tones) { return n_tones <= 32 ? "mix_small_kernel" : "mix_kernel"; }
 
 }  // namespace gsdr

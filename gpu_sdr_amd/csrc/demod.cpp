@@ -1080,7 +1080,7 @@ gsdr_demod *gsdr_demod_create(const gsdr_param_c *p) {
                 h->F = 1;
                 h->M = 1;
                 h->window.assign(1, 1.f);
-                h->kernel_name = gsdr::mix_kernel_name();
+                h->kernel_name = gsdr::mix_kernel_name(h->N);
                 rc = setup_ddc_common(h, 1, 1, (unsigned)p->rate, tone, 1, /*allow_flat=*/false);
                 h->capacity = (long long)h->N * h->L;
             }

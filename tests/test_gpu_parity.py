@@ -513,9 +513,12 @@ def test_direct_streaming_equals_one_long_buffer(cuda_device, gsdr_lib, engine):
 
 def test_direct_undecimated(cuda_device, gsdr_lib, oracle_mod):
     rng = np.random.default_rng(6)
-    for N, rate, L in [(3, 1000, 1000), (70, 1_000_000, 5000), (5, 200_000_000, 4099)]:
+    # (at most 32 tones: mix_small_kernel, several sample phases per wave; more: a lane per tone)
+    for N, rate, L in [(3, 1000, 1000), (70, 1_000_000, 5000), (5, 200_000_000, 4099), (1, 1000, 777), (2, 10_000, 2048),
+                       (8, 200_000_000, 100_003), (17, 1_000_000, 9000), (32, 1_000_000, 4096), (33, 1_000_000, 4096)]:
         freq = rng.integers(-rate // 2 + 1, rate // 2, size=N)
         dem = make_direct(freq, rate, 0, 4, L)
+        assert dem.kernel_name == ("mix_small_kernel" if N <= 32 else "mix_kernel")
         ref = oracle_mod.Direct(freq, rate, 0, 4, L)
         for c in range(3):
             x = crandn(rng, L)
