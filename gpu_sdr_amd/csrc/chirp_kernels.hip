@@ -16,6 +16,15 @@
 
 namespace gsdr {
 
+// (make_float2 of the HIP headers is not always_inline: inside a kernel with other target features --
+//  GSDR_NO_PK -- it would stay a real call)
+__device__ __forceinline__ float2 mk2c(float x, float y) {
+    float2 v;
+    v.x = x;
+    v.y = y;
+    return v;
+}
+
 // sin/cos of pi*index/2147483647.5 (ref: kernels.cu:421-422) from the int32
 // index.  pi*index/2147483647.5 == 2*pi*index/(2^32-1); replacing 2^32-1 by
 // 2^32 moves the angle by < 2^-33 turn (7e-10 rad), far below float
@@ -97,7 +106,7 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
     return __int_as_float(x);
 }
 
-__global__ __launch_bounds__(256) void chirp_demod_generic_kernel(const float2 *__restrict__ in,
+__global__ __launch_bounds__(256) GSDR_NO_PK void chirp_demod_generic_kernel(const float2 *__restrict__ in,
                                                           float2 *__restrict__ out, long long n,
                                                           unsigned long long index0,
                                                           ChirpShape cs) {
@@ -117,7 +126,7 @@ __global__ __launch_bounds__(256) void chirp_demod_generic_kernel(const float2 *
 }
 
 // One wave per output point v (4 per workgroup).
-__global__ __launch_bounds__(256) void chirp_lockin_generic_kernel(
+__global__ __launch_bounds__(256) GSDR_NO_PK void chirp_lockin_generic_kernel(
     const float2 *__restrict__ carry, int carry_len, const float2 *__restrict__ in,
     const float *__restrict__ profile, int ppt, int valid, float2 *__restrict__ out,
     unsigned long long index0, ChirpShape cs) {
@@ -138,12 +147,9 @@ __global__ __launch_bounds__(256) void chirp_lockin_generic_kernel(
         sx = fmaf(d.x, w, sx);
         sy = fmaf(d.y, w, sy);
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        sx += __shfl_xor(sx, off, 64);
-        sy += __shfl_xor(sy, off, 64);
-    }
-    if (lane == 0) out[v] = make_float2(sx, sy);
+    sx = wave_sum_to_lane63(sx);
+    sy = wave_sum_to_lane63(sy);
+    if (lane == 63) out[v] = mk2c(sx, sy);
 }
 
 // ---------------------------------------------------------------------------
@@ -198,7 +204,7 @@ __device__ __forceinline__ void load_stretch(ChirpStretch &c, const float2 *__re
     }
 }
 
-__global__ __launch_bounds__(256) void chirp_lockin_kernel(
+__global__ __launch_bounds__(256) GSDR_NO_PK void chirp_lockin_kernel(
     const float2 *__restrict__ carry, int carry_len, const float2 *__restrict__ in,
     const float *__restrict__ profile, int ppt, int decim, int valid, float2 *__restrict__ out,
     unsigned long long index0, ChirpShape cs) {
@@ -250,12 +256,12 @@ __global__ __launch_bounds__(256) void chirp_lockin_kernel(
     }
     sx = wave_sum_to_lane63(sx);
     sy = wave_sum_to_lane63(sy);
-    if (lane == 63) out[v] = make_float2(sx, sy);
+    if (lane == 63) out[v] = mk2c(sx, sy);
 }
 
 // Undecimated demodulation: 4 consecutive runs of 64 samples per wave; the step
 // index of a sample is the wave's base step plus a small quotient.
-__global__ __launch_bounds__(256) void chirp_demod_kernel(const float2 *__restrict__ in,
+__global__ __launch_bounds__(256) GSDR_NO_PK void chirp_demod_kernel(const float2 *__restrict__ in,
                                                           float2 *__restrict__ out, long long n,
                                                           unsigned long long index0,
                                                           ChirpShape cs) {

@@ -4,6 +4,13 @@
 
 #include <vector>
 
+// No packed FP32 (v_pk_*_f32) in a kernel that may share a SIMD with the matrix-core DDC loop of another
+// launch -- another handle on the same GPU, or the neighbouring buffer of this one: a v_pk_*_f32 with a
+// high-half broadcast returned stale values in some lanes while another wave of the SIMD ran an MFMA loop
+// (rule R3; tools/ubench_pk_hazard.hip; scratch/concurrent_handles.py shows it across
+// kernels).  Device helpers used by such a kernel must be always_inline.
+#define GSDR_NO_PK __attribute__((target("no-packed-fp32-ops")))
+
 namespace gsdr {
 
 // Shape of one DDC launch; passed to the kernels by value.

@@ -39,7 +39,7 @@
 namespace gsdr {
 
 template <int F, int K>
-__global__ __launch_bounds__(256) void ddc_kernel(
+__global__ __launch_bounds__(256) GSDR_NO_PK void ddc_kernel(
     const float2 *__restrict__ x,       // input samples, block b starts at x[b*M]
     const float *__restrict__ taps_t,   // [M][F]: taps_t[m*F+j] = h[j*M+m]
     const float2 *__restrict__ btab,    // [K][Npad]: w_n^lo
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void ddc_kernel(
 
     float2 A[F];  // A[k]: partial sum of output G = b + k while block b is processed
 #pragma unroll
-    for (int k = 0; k < F; ++k) A[k] = make_float2(0.f, 0.f);
+    for (int k = 0; k < F; ++k) { A[k].x = 0.f; A[k].y = 0.f; }
 
     const int nfull = M / K;
     const int R = M - nfull * K;
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void ddc_kernel(
         for (int q = 0; q < nfull; ++q, m += K) {
             float2 S[F];
 #pragma unroll
-            for (int j = 0; j < F; ++j) S[j] = make_float2(0.f, 0.f);
+            for (int j = 0; j < F; ++j) { S[j].x = 0.f; S[j].y = 0.f; }
 #pragma unroll
             for (int lo = 0; lo < K; ++lo) {
                 const float2 xs = xb[m + lo];  // wave-uniform -> SGPR pair
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void ddc_kernel(
         if (R) {
             float2 S[F];
 #pragma unroll
-            for (int j = 0; j < F; ++j) S[j] = make_float2(0.f, 0.f);
+            for (int j = 0; j < F; ++j) { S[j].x = 0.f; S[j].y = 0.f; }
 #pragma unroll
             for (int lo = 0; lo < K; ++lo) {
                 if (lo < R) {
@@ -146,7 +146,8 @@ __global__ __launch_bounds__(256) void ddc_kernel(
         if (b >= sh.g_off && n < N) out[(size_t)(b - sh.g_off) * N + n] = A[0];
 #pragma unroll
         for (int k = 0; k + 1 < F; ++k) A[k] = A[k + 1];
-        A[F - 1] = make_float2(0.f, 0.f);
+        A[F - 1].x = 0.f;
+        A[F - 1].y = 0.f;
     }
 
     if (F > 1) {
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(256) void ddc_kernel(
 
 // Adds the tail partial sums of chunk c-1 (or the stream carry, c == 0) to the
 // head outputs of chunk c.  Tiny: nch*(F-1)*Npad threads.
-__global__ void ddc_fixup(float2 *__restrict__ out, const float2 *__restrict__ tails,
+__global__ GSDR_NO_PK void ddc_fixup(float2 *__restrict__ out, const float2 *__restrict__ tails,
                           const float2 *__restrict__ carry_in, float2 *__restrict__ carry_out,
                           int F, DdcShape sh) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -200,7 +201,7 @@ __global__ void ddc_fixup(float2 *__restrict__ out, const float2 *__restrict__ t
 // ref: direct_demodulator_integer (kernels.cu:45-86) + cublasCgeam transpose
 // (USRP_demodulator.cpp:444-455).  HBM-write bound (8 B per tone-sample).
 template <int K>
-__global__ __launch_bounds__(256) void mix_kernel(
+__global__ __launch_bounds__(256) GSDR_NO_PK void mix_kernel(
     const float2 *__restrict__ x, const float2 *__restrict__ btab,
     const double2 *__restrict__ wk, const unsigned *__restrict__ fmod,
     float2 *__restrict__ out, DdcShape sh) {
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(256) void mix_kernel(
 // S consecutive samples x T tones -- 512 contiguous bytes when T == N.  Same tables, same arithmetic per
 // element (bit-identical to mix_kernel).
 template <int K>
-__global__ __launch_bounds__(256) void mix_small_kernel(
+__global__ __launch_bounds__(256) GSDR_NO_PK void mix_small_kernel(
     const float2 *__restrict__ x, const float2 *__restrict__ btab,
     const double2 *__restrict__ wk, const unsigned *__restrict__ fmod,
     float2 *__restrict__ out, DdcShape sh, int tshift) {

@@ -1250,6 +1250,14 @@ gsdr_demod *gsdr_demod_create(const gsdr_param_c *p) {
         fail_create(h, h->err.empty() ? "device setup failed" : h->err);
         return nullptr;
     }
+    // hipMemset returns before the fill has run (it is asynchronous on the null stream), and the streams
+    // of this library do not wait for the null stream: without this the zeroing of a carry buffer could
+    // land after the first call had written the carry (seen with several handles created and used from
+    // several threads, scratch/concurrent_handles.py: the second buffer of a TONES handle came out wrong)
+    if (hipStreamSynchronize(nullptr) != hipSuccess) {
+        fail_create(h, "device setup did not complete");
+        return nullptr;
+    }
     return h;
 }
 

@@ -29,7 +29,6 @@ namespace gsdr {
 // No packed FP32 in these kernels: a NOISE handle may run beside the matrix-core DDC of another handle
 // (two front-ends on one GPU), and v_pk_*_f32 with a high-half broadcast is unreliable in a wave that
 // shares its SIMD with an MFMA loop (rule R3, DESIGN.md section 4.1, tools/ubench_pk_hazard.hip).
-#define GSDR_NO_PK __attribute__((target("no-packed-fp32-ops")))
 
 namespace {
 

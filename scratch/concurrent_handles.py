@@ -1,0 +1,106 @@
+"""Two front-ends on one GPU: a heavy matrix-core DIRECT handle streams on one thread while handles of the
+other modes (chirp lock-in, TONES through the in-LDS FFT, a packed-FP32 DDC) run on their own threads and
+streams; every result of the small handles is compared with a reference result computed while the GPU was
+otherwise idle.  Looks for cross-kernel hazards (rule R3: packed FP32 beside an MFMA loop on one SIMD)."""
+import os, sys, threading, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import bench
+import gpu_sdr_amd as g
+
+dev = torch.device("cuda:0")
+rate = 200_000_000
+SECONDS = float(sys.argv[1]) if len(sys.argv) > 1 else 6.0
+
+
+def mk_chirp(L):
+    return g.RX_buffer_demodulator(g.param(mode="RX", rate=rate, buffer_len=L, decim=1, freq=[-rate // 2], chirp_f=[rate // 2],
+                                           swipe_s=[1_000_000], chirp_t=[1.0], wave_type=[g.w_type.CHIRP]), device_index=0)
+
+
+def mk_tones(L):
+    rng = np.random.default_rng(5)
+    freq = [int(f) for f in rng.choice(np.arange(-rate // 2 + 1, rate // 2), size=256, replace=False)]
+    return g.RX_buffer_demodulator(g.param(mode="RX", rate=rate, buffer_len=L, decim=0, pf_average=4, fft_tones=1230, freq=freq,
+                                           wave_type=[g.w_type.TONES] * 256), device_index=0)
+
+
+def mk_flat(L):
+    os.environ["GSDR_DDC_MFMA"] = "0"
+    try:
+        freq = [1_000_000 * (k + 1) for k in range(64)]
+        return g.RX_buffer_demodulator(g.param(mode="RX", rate=rate, buffer_len=L, decim=100, pf_average=4, freq=freq,
+                                               wave_type=[g.w_type.DIRECT] * 64), device_index=0)
+    finally:
+        del os.environ["GSDR_DDC_MFMA"]
+
+
+def mk_mix(L):
+    freq = [1_000_000 * (k + 1) for k in range(8)]
+    return g.RX_buffer_demodulator(g.param(mode="RX", rate=rate, buffer_len=L, decim=0, pf_average=1, freq=freq,
+                                           wave_type=[g.w_type.DIRECT] * 8), device_index=0)
+
+
+L = 200_000
+cases = {"chirp": mk_chirp, "tones": mk_tones, "flat": mk_flat, "mix": mk_mix}
+xs = [(torch.randn(L, device=dev) + 1j * torch.randn(L, device=dev)).to(torch.complex64) for _ in range(4)]
+NB = 12
+# reference pass: GPU otherwise idle; the stateful modes run the same NB buffers from a fresh handle every round
+refs = {}
+for name, mk in cases.items():
+    dem = mk(L)
+    out = torch.empty(dem.out_capacity, dtype=torch.complex64, device=dev)
+    r = []
+    for k in range(NB):
+        n = dem.process_device(xs[k % 4], out)
+        torch.cuda.synchronize()
+        r.append(out[:n].clone())
+    refs[name] = r
+    dem.close()
+
+stop = threading.Event()
+create_lock = threading.Lock()      # mk_flat() changes the environment: one creation at a time
+bad = {k: 0 for k in cases}
+rounds = {k: 0 for k in cases}
+
+
+def heavy():
+    eng = bench.HipEngine()
+    dem, bufs, outs, N = eng.build(bench.WORKLOADS["c3"], dev, 7)
+    k, pend = 0, 0
+    while not stop.is_set():
+        if pend == 3:
+            dem.wait(); pend -= 1
+        dem.submit_device(bufs[k % 8], outs[k % 3]); pend += 1; k += 1
+    while pend:
+        dem.wait(); pend -= 1
+    dem.close()
+    print("heavy: %d buffers of C3" % k, flush=True)
+
+
+def small(name):
+    st = torch.cuda.Stream(dev)
+    while not stop.is_set():
+        with create_lock:
+            dem = cases[name](L)
+        out = torch.empty(dem.out_capacity, dtype=torch.complex64, device=dev)
+        for k in range(NB):
+            n = dem.process_device(xs[k % 4], out, st)
+            st.synchronize()
+            if not torch.equal(out[:n], refs[name][k]):
+                bad[name] += 1
+                d = (out[:n] - refs[name][k]).abs()
+                print(name, "MISMATCH round", rounds[name], "buffer", k, "max abs diff", float(d.max()), "at", int(d.argmax()), flush=True)
+        dem.close()
+        rounds[name] += 1
+
+
+th = [threading.Thread(target=heavy)] + [threading.Thread(target=small, args=(n,)) for n in cases]
+for t in th:
+    t.start()
+time.sleep(SECONDS)
+stop.set()
+for t in th:
+    t.join()
+print("rounds", rounds, "mismatching buffers", bad, flush=True)
+sys.exit(1 if any(bad.values()) else 0)
