@@ -9,7 +9,9 @@
 // high-half broadcast returned stale values in some lanes while another wave of the SIMD ran an MFMA loop
 // (rule R3; tools/ubench_pk_hazard.hip; scratch/concurrent_handles.py shows it across
 // kernels).  Device helpers used by such a kernel must be always_inline.
+#ifndef GSDR_NO_PK        // (scratch/pk_hazard_ab.sh builds a variant with packed FP32 to show the hazard)
 #define GSDR_NO_PK __attribute__((target("no-packed-fp32-ops")))
+#endif
 
 namespace gsdr {
 

@@ -64,6 +64,30 @@ bad = {k: 0 for k in cases}
 rounds = {k: 0 for k in cases}
 
 
+def explain_chirp(k, v, got, want):
+    """which samples of point v would explain got - want?  (per-sample contributions from the numpy restatement)"""
+    from oracle import recipe_b
+    ns, length, chirpness, f0 = recipe_b.chirp_params(rate, -rate // 2, rate // 2, 1_000_000, 1.0)
+    ppt = length
+    x = xs[k % 4].cpu().numpy()
+    dm = recipe_b.chirp_demod(x, (k * L) % (ns * length), ns, length, chirpness, f0)
+    w = recipe_b.make_flat_window(ppt, ppt // 10)
+    c = dm[v * ppt:(v + 1) * ppt].astype(np.complex128) * w
+    d = got - want
+    print("   point", v, "got", got, "want", want, "sum of contributions", c.sum(), "diff", d)
+    best = []
+    for g0 in range(0, ppt, 16):
+        for span in (16, 32, 64):
+            sub = c[g0:g0 + span].sum()
+            for sign in (1, -1):
+                best.append((abs(d - sign * sub), sign, g0, span))
+    for s0 in range(ppt):
+        for sign in (1, -1, 2, -2):
+            best.append((abs(d - sign * c[s0]), sign, s0, 1))
+    best.sort()
+    print("   best explanations (residual, sign, first sample, span):", [(round(b[0], 6), b[1], b[2], b[3]) for b in best[:4]], flush=True)
+
+
 def heavy():
     eng = bench.HipEngine()
     dem, bufs, outs, N = eng.build(bench.WORKLOADS["c3"], dev, 7)
@@ -79,20 +103,29 @@ def heavy():
 
 
 def small(name):
+    # everything of this thread -- allocations, comparisons, the library's launches -- on ONE stream of its
+    # own: torch's caching allocator hands a freed block to the next taker on the stream it was allocated
+    # on, so a buffer allocated on the shared default stream and written through a side stream can be
+    # overwritten by another thread's pending default-stream kernel (it was: 0x01 bytes of a comparison
+    # result in the chirp output)
     st = torch.cuda.Stream(dev)
-    while not stop.is_set():
-        with create_lock:
-            dem = cases[name](L)
-        out = torch.empty(dem.out_capacity, dtype=torch.complex64, device=dev)
-        for k in range(NB):
-            n = dem.process_device(xs[k % 4], out, st)
-            st.synchronize()
-            if not torch.equal(out[:n], refs[name][k]):
-                bad[name] += 1
-                d = (out[:n] - refs[name][k]).abs()
-                print(name, "MISMATCH round", rounds[name], "buffer", k, "max abs diff", float(d.max()), "at", int(d.argmax()), flush=True)
-        dem.close()
-        rounds[name] += 1
+    with torch.cuda.stream(st):
+        while not stop.is_set():
+            with create_lock:
+                dem = cases[name](L)
+            out = torch.empty(dem.out_capacity, dtype=torch.complex64, device=dev)
+            for k in range(NB):
+                n = dem.process_device(xs[k % 4], out, st)
+                st.synchronize()
+                if not torch.equal(out[:n], refs[name][k]):
+                    bad[name] += 1
+                    d = (out[:n] - refs[name][k]).abs()
+                    print(name, "MISMATCH round", rounds[name], "buffer", k, "max abs diff", float(d.max()), "at", int(d.argmax()),
+                          "differing elements", int((d > 0).sum()), flush=True)
+                    if name == "chirp":
+                        explain_chirp(k, int(d.argmax()), complex(out[int(d.argmax())].item()), complex(refs[name][k][int(d.argmax())].item()))
+            dem.close()
+            rounds[name] += 1
 
 
 th = [threading.Thread(target=heavy)] + [threading.Thread(target=small, args=(n,)) for n in cases]

@@ -1429,3 +1429,108 @@ def test_describe_reports_the_engine_that_ran(cuda_device, gsdr_lib, monkeypatch
     assert d1["kernel"] == dem.kernel_name == "ddc_mfma_ring16_kernel" and d1["row_tiles_per_workgroup"] == 1
     assert "timing_build 0" in gsdr_lib.gsdr_build_info().decode()
     dem.close()
+
+
+def test_two_front_ends_on_one_gpu_do_not_disturb_each_other(cuda_device, gsdr_lib):
+    """The reference runs one demodulator per RX front-end, each on its own thread (A_RX2 and B_RX2 of one
+    board share the GPU).  A heavy matrix-core DIRECT handle streams on one thread while TONES (in-LDS FFT),
+    the undecimated mix and the chirp lock-in run on threads and streams of their own; every result of the
+    small handles must be bit-identical to what the same handle produces on an idle GPU.
+
+    What this guards: rule R3 of DESIGN.md section 4.1 holds ACROSS kernels -- a kernel in which the compiler
+    used v_pk_*_f32 returns wrong values now and then while a wave of the matrix-core loop shares its SIMD
+    (scratch/pk_hazard_ab.sh: 300+ wrong TONES buffers and 600+ wrong mix buffers in 15 s with packed FP32
+    allowed in those kernels, none with the shipped library, which compiles every product kernel that can
+    meet the loop with no-packed-fp32-ops) -- and that create() leaves no asynchronous initialisation
+    behind.  Each thread keeps allocations, comparisons and launches on ONE stream of its own (torch's
+    caching allocator reuses a freed block on the stream it was allocated on)."""
+    import threading
+    import time
+    import torch
+    import gpu_sdr_amd as g
+    rate, L, NB = 200_000_000, 200_000, 8
+    rng = np.random.default_rng(99)
+
+    def mk_chirp():
+        return make_chirp(rate, -rate // 2, rate // 2, 1_000_000, 1.0, 1, L)
+
+    tone_freq = rng.choice(np.arange(-rate // 2 + 1, rate // 2), size=256, replace=False)
+
+    def mk_tones():
+        return make_pfb(tone_freq, rate, 1230, 4, L)
+
+    def mk_mix():
+        return make_direct([1_000_000 * (k + 1) for k in range(8)], rate, 0, 1, L)
+
+    cases = {"chirp": mk_chirp, "tones": mk_tones, "mix": mk_mix}
+    xs = [torch.from_numpy(crandn(rng, L)).to(cuda_device) for _ in range(4)]
+    refs = {}
+    for name, mk in cases.items():
+        dem = mk()
+        out = torch.empty(dem.out_capacity, dtype=torch.complex64, device=cuda_device)
+        refs[name] = []
+        for k in range(NB):
+            n = dem.process_device(xs[k % 4], out)
+            torch.cuda.synchronize()
+            refs[name].append(out[:n].clone())
+        dem.close()
+    torch.cuda.synchronize()
+    stop, lock = threading.Event(), threading.Lock()
+    bad = {k: 0 for k in cases}
+    rounds = {k: 0 for k in cases}
+    heavy_n = [0]
+    errors = []
+
+    def heavy():
+        try:
+            freq = rng.choice(np.arange(-rate // 2 + 1, rate // 2), size=2048, replace=False)
+            with lock:
+                dem = make_direct(freq, rate, 1000, 4, 1_000_000)
+            st = torch.cuda.Stream(cuda_device)
+            with torch.cuda.stream(st):
+                x = torch.from_numpy(crandn(np.random.default_rng(1), 1_000_000)).to(cuda_device)
+                outs = [torch.empty(dem.out_capacity, dtype=torch.complex64, device=cuda_device) for _ in range(3)]
+                st.synchronize()
+                pend = 0
+                while not stop.is_set():
+                    if pend == 3:
+                        dem.wait()
+                        pend -= 1
+                    dem.submit_device(x, outs[heavy_n[0] % 3])
+                    pend += 1
+                    heavy_n[0] += 1
+                while pend:
+                    dem.wait()
+                    pend -= 1
+            dem.close()
+        except Exception as e:                      # pragma: no cover
+            errors.append(repr(e))
+
+    def small(name):
+        try:
+            st = torch.cuda.Stream(cuda_device)
+            with torch.cuda.stream(st):
+                while not stop.is_set():
+                    with lock:
+                        dem = cases[name]()
+                    out = torch.empty(dem.out_capacity, dtype=torch.complex64, device=cuda_device)
+                    for k in range(NB):
+                        n = dem.process_device(xs[k % 4], out, st)
+                        st.synchronize()
+                        if not torch.equal(out[:n], refs[name][k]):
+                            bad[name] += 1
+                    dem.close()
+                    rounds[name] += 1
+        except Exception as e:                      # pragma: no cover
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=heavy)] + [threading.Thread(target=small, args=(n,)) for n in cases]
+    for t in threads:
+        t.start()
+    time.sleep(5.0)
+    stop.set()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert heavy_n[0] > 1000 and all(r >= 5 for r in rounds.values()), (heavy_n, rounds)
+    assert bad == {k: 0 for k in cases}, (bad, rounds)
