@@ -277,6 +277,21 @@ def test_assembly_kernels_keep_two_waves_per_simd(gsdr_lib, tmp_path):
         dis = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", str(f)], check=True, capture_output=True, text=True).stdout
         bad = [ln.strip() for ln in dis.splitlines() if re.search(r"\b(flat_load|flat_store|scratch_load|scratch_store)", ln)]
         assert not bad, (f.name, bad[:4])
+        # and packed FP32 only where it is meant to be: a wave executing v_pk_*_f32 returns stale values now
+        # and then while a wave of the matrix-core loop shares its SIMD (rule 3 --
+        # across kernels of concurrently used handles too), so every kernel that can meet that loop is built
+        # with no-packed-fp32-ops.  Exempt: the packed-FP32 DDC itself (engine of GSDR_DDC_MFMA=0), the
+        # compiler-scheduled matrix-core kernel (A/B runs only) and the synthetic sources of bench.py
+        sym, packed = "?", {}
+        for ln in dis.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", ln)
+            if m:
+                sym = m.group(1)
+            elif re.search(r"\bv_pk_[a-z]+_f32\b", ln):
+                packed[sym] = packed.get(sym, 0) + 1
+        allowed = ("ddc_flat_kernel", "ddc_mfma_kernelILi", "source_tones_kernel", "source_chirp_kernel")
+        offenders = {k: v for k, v in packed.items() if not any(a in k for a in allowed)}
+        assert not offenders, (f.name, offenders)
 
 
 def test_pfb_lds_stage_plan(gsdr_lib):
