@@ -202,7 +202,7 @@ struct PfbLdsArgs {
     unsigned mag_n, mag_nout;
     unsigned mag_t[16], mag_p[16];     // per stage: t = n / R, p = product of the earlier radices
     int stage_t[16], stage_tws[16];    // per stage: t and n / (p R), so that no stage divides at run time
-    unsigned mag_t4, mag_rt4;          // prime-first stage: t4 = ceil(t / 4), R * t4
+    unsigned mag_t4;                   // prime-first stage: t4 = ceil(t / 4)
 };
 
 __device__ __forceinline__ int fdiv(int x, unsigned magic) {
@@ -246,7 +246,7 @@ __device__ __forceinline__ void lds_stage(const float2 *src, float2 *dst, int n,
 // of the plain sum (which cost 11 of the 27 us of a 1230 = 41*2*3*5-point buffer).  One q and four
 // consecutive columns i per work item; roots: w_R^m = (cos, -sin)(2 pi m / R), m < R, in the LDS.
 __device__ __forceinline__ void lds_stage_prime_first(int R, float2 *src, float2 *dst, int n, const float2 *roots,
-                                                      int t, unsigned mag_t, unsigned mag_t4, unsigned mag_rt4, int FR, int tid, int NT) {
+                                                      int t, unsigned mag_t, unsigned mag_t4, int FR, int tid, int NT) {
     const int t4 = (t + 3) >> 2, h = (R - 1) >> 1;
     // pass 1: S and D in place
     for (int g = tid; g < FR * h * t; g += NT) {
@@ -260,7 +260,6 @@ __device__ __forceinline__ void lds_stage_prime_first(int R, float2 *src, float2
     __syncthreads();
     // pass 2: q = 0 .. h; work item = (frame, q, group of four columns)
     const int items = (h + 1) * t4;
-    (void)mag_rt4;
     for (int g = tid; g < FR * items; g += NT) {
         const int fr = FR == 1 ? 0 : g / items, rem = g - fr * items;
         const int q = fdiv(rem, mag_t4), i0 = (rem - q * t4) << 2;
@@ -442,7 +441,7 @@ __global__ __launch_bounds__(NT) GSDR_NO_PK void pfb_lds_kernel(const PfbLdsArgs
             case 13: lds_stage<13>(src, dst, n, p, st, stw, mt, mp, tw, FR, tid, NT); break;
             default:
                 if (s == 0)
-                    lds_stage_prime_first(R, src, dst, n, roots, st, mt, a.mag_t4, a.mag_rt4, FR, tid, NT);
+                    lds_stage_prime_first(R, src, dst, n, roots, st, mt, a.mag_t4, FR, tid, NT);
                 else
                     lds_stage_generic(R, src, dst, n, p, tw, FR, tid, NT);
                 break;
@@ -744,7 +743,6 @@ hipError_t launch_pfb_lds(const float2 *carry, int new_0, const float2 *in, cons
         if (a.n_radices > 0 && a.radices[0] > 13) {
             const int t4 = (nfft / a.radices[0] + 3) / 4;
             a.mag_t4 = magic(t4);
-            a.mag_rt4 = magic((long long)a.radices[0] * t4);
         }
     }
     a.blocks_per_xcd = (a.main_blocks + 7u) / 8u;
