@@ -234,7 +234,7 @@ int main(int argc, char **argv) {
     // ---- rx_single_link, link_threads.cpp:647-690 ----
     size_t recv_samples = 0;
     double worst_ms = 0, worst_steady_ms = 0;
-    long long worst_at = -1, call_no = 0;
+    long long worst_at = -1, call_no = 0, calls_above_3ms = 0;
     const auto t0 = std::chrono::steady_clock::now();
     std::queue<std::pair<RX_wrapper, float2 *>> in_flight;  // pipelined mode: submitted, not yet waited for
     auto retire = [&] {
@@ -263,6 +263,7 @@ int main(int argc, char **argv) {
         }
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
         if (ms > worst_ms) { worst_ms = ms; worst_at = call_no; }
+        if (ms > 3.0) calls_above_3ms++;
         if (call_no >= 2 * GSDR_PIPELINE_DEPTH && ms > worst_steady_ms) worst_steady_ms = ms;
         call_no++;
     }
@@ -275,10 +276,10 @@ int main(int argc, char **argv) {
     const double msps = (double)recv_samples / sec / 1e6;
     std::printf("{\"harness\": \"rx_single_link%s\", \"tones\": %d, \"decim\": %d, \"buffers\": %d, "
                 "\"msamples_per_s_pcie_inclusive\": %.1f, \"ms_per_buffer\": %.3f, \"worst_ms\": %.3f, \"worst_at_call\": %lld, "
-                "\"worst_ms_after_first_%d_calls\": %.3f, "
+                "\"worst_ms_after_first_%d_calls\": %.3f, \"calls_above_3ms\": %lld, "
                 "\"realtime_factor_200Msps\": %.2f, \"streamed_samples\": %lld}\n",
                 pipelined ? " (submit/wait)" : "", n_tones, decim, n_buffers, msps, sec / n_buffers * 1e3, worst_ms, worst_at,
-                2 * GSDR_PIPELINE_DEPTH, worst_steady_ms, msps / 200.0,
+                2 * GSDR_PIPELINE_DEPTH, worst_steady_ms, calls_above_3ms, msps / 200.0,
                 streamed.load());
     for (int i = 0; i < pool; ++i) { (void)hipHostFree(in_pool[i]); (void)hipHostFree(out_pool[i]); }
     return 0;
