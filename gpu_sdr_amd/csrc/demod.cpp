@@ -316,9 +316,12 @@ int setup_ddc_common(gsdr_demod *h, int F, int M, unsigned rate,
     if (h->ddc_channels <= 0) h->ddc_channels = h->N;
     h->Npad = ((h->ddc_channels + 63) / 64) * 64;
     h->TW = h->Npad / 64;
-    // ddc_flat_kernel (packed math, pipelined scalar loads) covers F <= 4;
-    // ddc_kernel is the generic fallback (and GSDR_DDC_PIPE=0 forces it, for A/B runs)
-    h->pipe = allow_flat && env_int("GSDR_DDC_PIPE", 1) != 0 && F <= 4;
+    // ddc_flat_kernel (packed math, pipelined scalar loads) covers F <= 4 and is the engine of
+    // GSDR_DDC_MFMA=0, where no matrix-core loop runs on the GPU at all.  With the matrix cores enabled,
+    // a shape they do not take (windows shorter than a buffer row, ...) goes to the generic ddc_kernel:
+    // it is compiled without packed FP32, which is not safe beside the matrix-core loop of another
+    // handle on the same GPU (rule 3).  GSDR_DDC_PIPE=0 forces the generic kernel.
+    h->pipe = allow_flat && env_int("GSDR_DDC_PIPE", 1) != 0 && F <= 4 && env_int("GSDR_DDC_MFMA", 1) == 0;
     if (h->pipe) {
         // sub-block length: whole sub-blocks per block, cheapest total
         // (padded samples + ~3.3 sample-equivalents of fold work per sub-block)
