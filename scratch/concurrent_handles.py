@@ -41,8 +41,15 @@ def mk_mix(L):
                                            wave_type=[g.w_type.DIRECT] * 8), device_index=0)
 
 
+def mk_direct(L):
+    rng = np.random.default_rng(11)
+    freq = [int(f) for f in rng.choice(np.arange(-rate // 2 + 1, rate // 2), size=256, replace=False)]
+    return g.RX_buffer_demodulator(g.param(mode="RX", rate=rate, buffer_len=L, decim=100, pf_average=4, freq=freq,
+                                           wave_type=[g.w_type.DIRECT] * 256), device_index=0)
+
+
 L = 200_000
-cases = {"chirp": mk_chirp, "tones": mk_tones, "flat": mk_flat, "mix": mk_mix}
+cases = {"chirp": mk_chirp, "tones": mk_tones, "flat": mk_flat, "mix": mk_mix, "direct": mk_direct}
 xs = [(torch.randn(L, device=dev) + 1j * torch.randn(L, device=dev)).to(torch.complex64) for _ in range(4)]
 NB = 12
 # reference pass: GPU otherwise idle; the stateful modes run the same NB buffers from a fresh handle every round

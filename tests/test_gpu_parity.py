@@ -1434,7 +1434,7 @@ def test_describe_reports_the_engine_that_ran(cuda_device, gsdr_lib, monkeypatch
 def test_two_front_ends_on_one_gpu_do_not_disturb_each_other(cuda_device, gsdr_lib):
     """The reference runs one demodulator per RX front-end, each on its own thread (A_RX2 and B_RX2 of one
     board share the GPU).  A heavy matrix-core DIRECT handle streams on one thread while TONES (in-LDS FFT),
-    the undecimated mix and the chirp lock-in run on threads and streams of their own; every result of the
+    the undecimated mix, the chirp lock-in and a second DIRECT handle run on threads and streams of their own; every result of the
     small handles must be bit-identical to what the same handle produces on an idle GPU.
 
     What this guards: rule R3 of DESIGN.md section 4.1 holds ACROSS kernels -- a kernel in which the compiler
@@ -1462,7 +1462,12 @@ def test_two_front_ends_on_one_gpu_do_not_disturb_each_other(cuda_device, gsdr_l
     def mk_mix():
         return make_direct([1_000_000 * (k + 1) for k in range(8)], rate, 0, 1, L)
 
-    cases = {"chirp": mk_chirp, "tones": mk_tones, "mix": mk_mix}
+    direct_freq = rng.choice(np.arange(-rate // 2 + 1, rate // 2), size=256, replace=False)
+
+    def mk_direct():                                   # a second matrix-core front-end
+        return make_direct(direct_freq, rate, 100, 4, L)
+
+    cases = {"chirp": mk_chirp, "tones": mk_tones, "mix": mk_mix, "direct": mk_direct}
     xs = [torch.from_numpy(crandn(rng, L)).to(cuda_device) for _ in range(4)]
     refs = {}
     for name, mk in cases.items():
@@ -1532,5 +1537,5 @@ def test_two_front_ends_on_one_gpu_do_not_disturb_each_other(cuda_device, gsdr_l
     for t in threads:
         t.join()
     assert not errors, errors
-    assert heavy_n[0] > 1000 and all(r >= 5 for r in rounds.values()), (heavy_n, rounds)
+    assert heavy_n[0] > 1000 and all(r >= 3 for r in rounds.values()), (heavy_n, rounds)
     assert bad == {k: 0 for k in cases}, (bad, rounds)
