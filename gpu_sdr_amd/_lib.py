@@ -105,6 +105,9 @@ SIGNATURES = [
     ("gsdr_pfb_tone_bins", None, [C.c_int, C.c_int, _ip, C.c_int, _ip]),
     ("gsdr_pfb_batching", C.c_int, [C.c_longlong, C.c_int, C.c_longlong]),
     ("gsdr_pfb_lds_stages", C.c_int, [C.c_int, C.POINTER(C.c_int)]),
+    ("gsdr_txgen_tones_create", C.c_void_p, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int]),
+    ("gsdr_txgen_tones_fill", C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong, C.c_void_p]),
+    ("gsdr_txgen_close", None, [C.c_void_p]),
     ("gsdr_chirp_derive", None, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                  C.POINTER(ChirpParamC)]),
     ("gsdr_command_parse", _vp, [C.c_char_p, C.c_int]),

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include "ddc_kernels.h"
+#include "ddc_device.h"
 
 namespace gsdr {
 
@@ -384,6 +385,88 @@ __global__ __launch_bounds__(256) void source_chirp_kernel(float2 *__restrict__ 
         sincos_index(chirp_index(e, cs, small), s, c);
         out[o] = make_float2(s * scale, -c * scale);  // ref: kernels.cu:367-368
     }
+}
+
+// ---------------------------------------------------------------------------
+// TX tone comb at scale (row f3): x[s] = sum_k a_k e^(i phi_k) w_k^s, w_k = e^(+2 pi i f_k / rate).
+// ref: tone_gen, cpp/kernels.cu:589-684, builds one period (`rate` samples: 1.6 GB at 200 Msps) by an
+// inverse FFT at set-up and TX_buffer_generator::get_from_tones serves slices of it
+// (cpp/USRP_buffer_generator.cpp:226-229).  Here a buffer is synthesised when it is asked for, fast
+// enough for that (2048 tones: 0.3 ms per 1 Mi samples, 17 x real time at 200 Msps), from exact integer
+// phases -- no period in memory, no drift:
+//   1024 consecutive samples at a time, s = s0 + 64 j + lane:  w^s = w^s0 * w^lane * w^(64 j);
+//   w^s0 comes exactly (integer phase f s0 mod rate, double sincos) once per tone and wave -- 64 tones at a
+//   time, one per lane, handed round with v_readlane --, w^lane from a table B[k][64], w^(64 j) from a
+//   table C[k][16] through scalar loads: T = (a_k e^(i phi_k) w^s0) B[k][lane], then 16 complex
+//   multiply-adds acc[j] += T C[k][j] with scalar second operands.  ~80 vector instructions per tone and
+//   1024 samples; the per-sample sincos of source_tones_kernel (bench.py's noisy input) is 70 x that.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) GSDR_NO_PK void tones_synth_kernel(
+    float2 *__restrict__ out, long long n, unsigned long long start, unsigned rate, unsigned long long rate_magic,
+    double inv_rate, const unsigned *__restrict__ fmod, const float2 *__restrict__ q0,
+    const float2 *__restrict__ btab, const float2 *__restrict__ ctab, int n_tones) {
+    // a workgroup makes 1024 consecutive samples; its four waves share the tones (chunks of 64 tones go
+    // round the waves) and add their partial sums through the LDS: four times the waves of a wave-per-
+    // stretch layout, which at one wave per SIMD was a bare latency chain (2048 tones: 708 us per buffer)
+    __shared__ float2 part[4][16][64];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long base = (long long)blockIdx.x * 1024;
+    const unsigned long long s0 = mod_rate(start + (unsigned long long)base, rate, rate_magic);   // start < rate, base < 2^62
+    float ax[16], ay[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) ax[j] = ay[j] = 0.f;
+    for (int k0 = wid * 64; k0 < n_tones; k0 += 256) {
+        const int kl = k0 + lane < n_tones ? k0 + lane : n_tones - 1;
+        const unsigned long long ph = mod_rate((unsigned long long)fmod[kl] * s0, rate, rate_magic);
+        double re, im;
+        exact_phasor(ph, inv_rate, re, im);                     // e^(-2 pi i ph / rate): the TX sign is the other one
+        const float2 a = q0[kl];
+        const float wr = (float)re, wi = -(float)im;
+        const int Qx = __float_as_int(a.x * wr - a.y * wi), Qy = __float_as_int(a.x * wi + a.y * wr);
+        const int cnt = n_tones - k0 < 64 ? n_tones - k0 : 64;
+        for (int t = 0; t < cnt; ++t) {
+            const float qx = __int_as_float(__builtin_amdgcn_readlane(Qx, t)), qy = __int_as_float(__builtin_amdgcn_readlane(Qy, t));
+            const float2 B = btab[(size_t)(k0 + t) * 64 + lane];
+            const float tx = qx * B.x - qy * B.y, ty = qx * B.y + qy * B.x;
+            const float2 *C = ctab + (size_t)(k0 + t) * 16;      // uniform address: scalar loads
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float2 c = C[j];
+                ax[j] = fmaf(tx, c.x, fmaf(-ty, c.y, ax[j]));
+                ay[j] = fmaf(tx, c.y, fmaf(ty, c.x, ay[j]));
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) part[wid][j][lane] = mk2c(ax[j], ay[j]);
+    __syncthreads();
+    // wave w adds the four partial sums of stretches j = 4 w .. 4 w + 3 (in wave order: a fixed summation order)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int j = wid * 4 + jj;
+        float sx = 0.f, sy = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float2 v = part[w][j][lane];
+            sx += v.x;
+            sy += v.y;
+        }
+        const long long s = base + 64 * j + lane;
+        if (s < n) out[s] = mk2c(sx, sy);
+    }
+}
+
+hipError_t launch_tones_synth(float2 *out, long long n, unsigned long long start, unsigned rate, const unsigned *fmod,
+                              const float2 *q0, const float2 *btab, const float2 *ctab, int n_tones, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    if (!out || rate < 1 || start >= rate || n_tones < 0 || (n_tones > 0 && (!fmod || !q0 || !btab || !ctab)))
+        return hipErrorInvalidValue;
+    const unsigned long long magic = ~0ULL / rate;
+    const long long groups = (n + 1023) / 1024;
+    hipLaunchKernelGGL(tones_synth_kernel, dim3((unsigned)groups), dim3(256), 0, st, out, n, start, rate, magic,
+                       1.0 / (double)rate, fmod, q0, btab, ctab, n_tones);
+    return hipGetLastError();
 }
 
 hipError_t launch_source_tones(float2 *out, long long n, long long start, unsigned rate,

@@ -181,6 +181,10 @@ hipError_t launch_chirp_lockin(const float2 *carry, int carry_len, const float2 
                                const float *profile, int ppt, int valid, float2 *out,
                                unsigned long long index0, const ChirpShape &cs, hipStream_t st);
 hipError_t launch_warm(hipStream_t st);
+// TX tone comb: out[s] = sum_k q0[k] w_k^(start + s), s < n; fmod = f mod rate, btab[k][64] = w_k^lo,
+// ctab[k][16] = w_k^(64 j), w_k = e^(+2 pi i f_k / rate) (ref: tone_gen, cpp/kernels.cu:589-684)
+hipError_t launch_tones_synth(float2 *out, long long n, unsigned long long start, unsigned rate, const unsigned *fmod,
+                              const float2 *q0, const float2 *btab, const float2 *ctab, int n_tones, hipStream_t st);
 const char *chirp_demod_kernel_name();
 const char *chirp_lockin_kernel_name();
 

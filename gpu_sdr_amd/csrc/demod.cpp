@@ -1762,6 +1762,88 @@ int gsdr_source_tones(gsdr_c64 *out_dev, long long n, long long start, int rate,
     return 0;
 }
 
+// ---- TX tone comb at scale (row f3) ------------------------------------------
+struct gsdr_txgen {
+    int device = -1;
+    unsigned rate = 1;
+    int n_tones = 0;
+    unsigned *d_fmod = nullptr;
+    float2 *d_q0 = nullptr, *d_btab = nullptr, *d_ctab = nullptr;
+};
+
+gsdr_txgen *gsdr_txgen_tones_create(int rate, const int *freq, const float *ampl, const float *phase, int n_tones,
+                                    int device_index) {
+    g_create_error.clear();
+    if (rate <= 0 || n_tones < 0 || (n_tones > 0 && (!freq || !ampl))) {
+        g_create_error = "gsdr_txgen_tones_create: bad arguments";
+        return nullptr;
+    }
+    if (device_index >= 0 && hipSetDevice(device_index) != hipSuccess) {
+        g_create_error = "gsdr_txgen_tones_create: hipSetDevice failed (no such GPU?)";
+        return nullptr;
+    }
+    gsdr_txgen *g = new gsdr_txgen();
+    g->device = device_index;
+    g->rate = (unsigned)rate;
+    g->n_tones = n_tones;
+    const size_t N = (size_t)(n_tones > 0 ? n_tones : 1);
+    std::vector<unsigned> fm(N, 0u);
+    std::vector<float2> q0(N, make_float2(0.f, 0.f)), bt(N * 64), ct(N * 16);
+    for (int k = 0; k < n_tones; ++k) {
+        long long r = (long long)freq[k] % rate;
+        if (r < 0) r += rate;
+        fm[(size_t)k] = (unsigned)r;
+        const double ph0 = phase ? (double)phase[k] : 0.0;
+        q0[(size_t)k] = make_float2((float)((double)ampl[k] * std::cos(ph0)), (float)((double)ampl[k] * std::sin(ph0)));
+        // w^m for the exact integer phase (f m) mod rate, TX sign: e^(+2 pi i ...)
+        auto w = [&](unsigned long long m) {
+            double re, im;
+            phasor(((unsigned long long)r * m) % (unsigned long long)rate, (unsigned)rate, re, im);   // e^(-...)
+            return make_float2((float)re, (float)-im);
+        };
+        for (int lo = 0; lo < 64; ++lo) bt[(size_t)k * 64 + lo] = w((unsigned long long)lo);
+        for (int j = 0; j < 16; ++j) ct[(size_t)k * 16 + j] = w(64ULL * (unsigned long long)j);
+    }
+    const bool ok = upload(&g->d_fmod, fm) == hipSuccess && upload(&g->d_q0, q0) == hipSuccess &&
+                    upload(&g->d_btab, bt) == hipSuccess && upload(&g->d_ctab, ct) == hipSuccess &&
+                    hipStreamSynchronize(nullptr) == hipSuccess;
+    if (!ok) {
+        g_create_error = "gsdr_txgen_tones_create: device allocation failed";
+        gsdr_txgen_close(g);
+        return nullptr;
+    }
+    return g;
+}
+
+int gsdr_txgen_tones_fill(gsdr_txgen *g, gsdr_c64 *out_dev, long long n, long long start, void *hip_stream) {
+    if (!g || !out_dev || n < 0) {
+        g_create_error = "gsdr_txgen_tones_fill: bad arguments";
+        return -1;
+    }
+    if (g->device >= 0 && hipSetDevice(g->device) != hipSuccess) {
+        g_create_error = "gsdr_txgen_tones_fill: hipSetDevice failed";
+        return -1;
+    }
+    long long sm = start % (long long)g->rate;
+    if (sm < 0) sm += g->rate;
+    const hipError_t e = gsdr::launch_tones_synth(reinterpret_cast<float2 *>(out_dev), n, (unsigned long long)sm, g->rate,
+                                                  g->d_fmod, g->d_q0, g->d_btab, g->d_ctab, g->n_tones, (hipStream_t)hip_stream);
+    if (e != hipSuccess) {
+        g_create_error = std::string("gsdr_txgen_tones_fill: ") + hipGetErrorString(e);
+        return -1;
+    }
+    return 0;
+}
+
+void gsdr_txgen_close(gsdr_txgen *g) {
+    if (!g) return;
+    if (g->device >= 0) (void)hipSetDevice(g->device);
+    (void)hipDeviceSynchronize();
+    for (void *p : {(void *)g->d_fmod, (void *)g->d_q0, (void *)g->d_btab, (void *)g->d_ctab})
+        if (p) (void)hipFree(p);
+    delete g;
+}
+
 int gsdr_source_chirp(gsdr_c64 *out_dev, long long n, unsigned long long last_index,
                       const gsdr_chirp_param *cp, float scale, void *hip_stream) {
     if (!out_dev || !cp || n < 0 || cp->num_steps < 1 || cp->length < 1) return -1;

@@ -76,6 +76,10 @@ class TX_buffer_generator:
             # TONES_buffer_len: rate, or the multiple of it that holds one buffer (:60-75)
             self._period = int(p.rate) * max(1, -(-self.buffer_len // int(p.rate)))
             self._last = 0            # TONES_last_sample
+            # the device-side generator (gsdr_txgen_*): tables once, every buffer synthesised on demand
+            import ctypes as C
+            self._tx = None
+            self._device = None
         else:  # CHIRP
             cp = chirp_derive(p.rate, p.freq[0], p.chirp_f[0], p.swipe_s[0], p.chirp_t[0])
             # the TX side also resets num_steps when a step would be shorter than one
@@ -88,12 +92,37 @@ class TX_buffer_generator:
 
     def get(self, out_tensor, stream=None) -> None:
         if self.mode == w_type.TONES:
-            device_tones(out_tensor, self._last, int(self.parameters.rate), self._freq, self._ampl,
-                         self._phase, sigma=0.0, stream=stream)
+            import ctypes as C
+            import torch
+            assert out_tensor.is_cuda and out_tensor.dtype == torch.complex64 and out_tensor.is_contiguous()
+            L = _lib.lib()
+            if self._tx is None:
+                f = np.ascontiguousarray(self._freq, dtype=np.int32)
+                a = np.ascontiguousarray(self._ampl, dtype=np.float32)
+                ph = np.ascontiguousarray(self._phase, dtype=np.float32)
+                self._device = out_tensor.device
+                self._tx = L.gsdr_txgen_tones_create(int(self.parameters.rate), f.ctypes.data_as(C.POINTER(C.c_int)),
+                                                     a.ctypes.data_as(C.POINTER(C.c_float)), ph.ctypes.data_as(C.POINTER(C.c_float)),
+                                                     len(f), self._device.index if self._device.index is not None else 0)
+                if not self._tx:
+                    raise GsdrError(L.gsdr_last_error(None).decode())
+            if stream is None:
+                stream = torch.cuda.current_stream(out_tensor.device)
+            if L.gsdr_txgen_tones_fill(self._tx, out_tensor.data_ptr(), out_tensor.numel(), int(self._last),
+                                       C.c_void_p(stream.cuda_stream)) != 0:
+                raise GsdrError(L.gsdr_last_error(None).decode())
             self._last = (self._last + self.buffer_len) % self._period
         else:
             device_chirp(out_tensor, self._last, self._cp, scale=self._scale, stream=stream)
             self._last = (self._last + self.buffer_len) % (self._cp.num_steps * self._cp.length)
 
     def close(self) -> None:
-        pass
+        if getattr(self, "_tx", None):
+            _lib.lib().gsdr_txgen_close(self._tx)
+            self._tx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

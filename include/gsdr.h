@@ -289,6 +289,20 @@ int gsdr_source_tones(gsdr_c64 *out_dev, long long n, long long start, int rate,
  * (ref: TX_buffer_generator TONES, cpp/USRP_buffer_generator.cpp:60-95,226-229). */
 int gsdr_tx_tone_bins(int rate, const int *freq, const float *ampl, int n,
                       int *out_freq, float *out_ampl);
+
+/* TX tone comb generator at scale (row f3).  ref: tone_gen (cpp/kernels.cu:589-684) builds one period of
+ * `rate` samples by an inverse FFT when the generator is set up and TX_buffer_generator::get_from_tones
+ * (cpp/USRP_buffer_generator.cpp:226-229) serves slices of it; this generator synthesises every buffer on
+ * demand from exact integer phases (no 1.6 GB period at 200 Msps), faster than the stream needs it
+ * (2048 tones: 17 x real time at 200 Msps).  freq/ampl are the tones gsdr_tx_tone_bins() returned (signed Hz,
+ * one per bin), phase their initial phases in radians (NULL = 0).  x[s] = sum_k ampl_k e^(i phase_k)
+ * e^(+2 pi i freq_k s / rate).  gsdr_txgen_tones_fill writes samples start .. start + n - 1 (start taken
+ * mod rate) into device memory on hip_stream; asynchronous.  Returns 0 / -1 (gsdr_last_error(NULL)). */
+typedef struct gsdr_txgen gsdr_txgen;
+gsdr_txgen *gsdr_txgen_tones_create(int rate, const int *freq, const float *ampl, const float *phase, int n_tones,
+                                    int device_index);
+int gsdr_txgen_tones_fill(gsdr_txgen *g, gsdr_c64 *out_dev, long long n, long long start, void *hip_stream);
+void gsdr_txgen_close(gsdr_txgen *g);
 /* TX chirp law (ref: chirp_gen, cpp/kernels.cu:335-372) written to device. */
 int gsdr_source_chirp(gsdr_c64 *out_dev, long long n, unsigned long long last_index,
                       const gsdr_chirp_param *cp, float scale, void *hip_stream);

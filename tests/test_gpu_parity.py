@@ -1349,6 +1349,35 @@ def test_tx_tone_generator_against_oracle(cuda_device, gsdr_lib, oracle_mod):
         tx.close()
 
 
+def test_tx_tone_generator_at_scale(cuda_device, gsdr_lib):
+    """TX_buffer_generator(TONES) with 2048 and 300 tones at 200 Msps (gsdr_txgen_*: exact phase once per tone
+    and 1024 samples, two table factors for the rest) against the per-sample synthesis of the input source
+    (one float sincos of an exact integer phase per tone and sample), buffer by buffer across the wrap of the
+    sample index at `rate`; and a buffer length that is no multiple of 1024."""
+    import torch
+    import gpu_sdr_amd as g
+    from gpu_sdr_amd.source import device_tones, tone_comb
+    rate = 200_000_000
+    for N, L, nbuf in [(2048, 150_000, 3), (300, 99_999, 4)]:
+        freq, ampl, phase = tone_comb(N, rate, 17)
+        tx = g.TX_buffer_generator(g.param(mode="TX", rate=rate, buffer_len=L, freq=[int(f) for f in freq],
+                                           ampl=[float(a) for a in ampl], wave_type=[g.w_type.TONES] * N))
+        tx._last = rate - L - 1234          # the third buffer straddles the wrap at `rate`
+        from gpu_sdr_amd.generator import tone_bins
+        f2, a2 = tone_bins(freq, ampl, rate)
+        x = torch.empty(L, dtype=torch.complex64, device=cuda_device)
+        want = torch.empty(L, dtype=torch.complex64, device=cuda_device)
+        for c in range(nbuf):
+            start = tx._last
+            tx.get(x)
+            device_tones(want, start, rate, f2, a2, np.zeros(len(f2), dtype=np.float32), sigma=0.0)
+            torch.cuda.synchronize()
+            err = float((x - want).abs().max())
+            record_margin(err / float(np.sum(a2)), "max abs error / sum of amplitudes")
+            assert err <= 2e-6 * float(np.sum(a2)), (N, c, err)
+        tx.close()
+
+
 def test_sw_loop_tx_chirp_into_rx_chirp(cuda_device, gsdr_lib):
     """TX chirp generator -> RX chirp demodulator with lock-in: a flat S21 = ampl."""
     import torch
