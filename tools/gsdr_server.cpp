@@ -84,6 +84,7 @@ struct FrontEnd {            // one RX demodulator fed by its TX generator (or s
     gsdr_antenna_info rxi{}, txi{};
     bool has_tx = false;
     gsdr_chirp_param tx_chirp{};
+    gsdr_txgen *tx_tones = nullptr;   // TX tone comb generator (created with the first buffer)
     char code = 'B';
     gsdr_c64 *d_in = nullptr, *d_out = nullptr, *h_out = nullptr;
     long long produced = 0;   // TX sample counter
@@ -149,12 +150,23 @@ static bool run_measurement(const gsdr_command *cmd, int data_fd, int device) {
                     ok = false;
                     break;
                 }
-                // the tones the reference's tone_gen really produces (bin assignment, kernels.cu:617-635)
-                std::vector<int> tf((size_t)F.tx.n_wave_type);
-                std::vector<float> ta((size_t)F.tx.n_wave_type), phase((size_t)F.tx.n_wave_type, 0.f);
-                const int nt = gsdr_tx_tone_bins(F.tx.rate, F.tx.freq, F.txi.ampl, F.tx.n_wave_type, tf.data(), ta.data());
-                gsdr_source_tones(F.d_in, L, F.produced, F.tx.rate, tf.data(), ta.data(), phase.data(),
-                                  nt > 0 ? nt : 0, 0.f, 0, nullptr);
+                if (!F.tx_tones) {
+                    // the tones the reference's tone_gen really produces (bin assignment, kernels.cu:617-635)
+                    std::vector<int> tf((size_t)F.tx.n_wave_type);
+                    std::vector<float> ta((size_t)F.tx.n_wave_type);
+                    const int nt = gsdr_tx_tone_bins(F.tx.rate, F.tx.freq, F.txi.ampl, F.tx.n_wave_type, tf.data(), ta.data());
+                    F.tx_tones = gsdr_txgen_tones_create(F.tx.rate, tf.data(), ta.data(), nullptr, nt > 0 ? nt : 0, device);
+                    if (!F.tx_tones) {
+                        std::fprintf(stderr, "ERROR: TX generator: %s\n", gsdr_last_error(nullptr));
+                        ok = false;
+                        break;
+                    }
+                }
+                if (gsdr_txgen_tones_fill(F.tx_tones, F.d_in, L, F.produced, nullptr) != 0) {
+                    std::fprintf(stderr, "ERROR: TX generator: %s\n", gsdr_last_error(nullptr));
+                    ok = false;
+                    break;
+                }
             } else if (F.has_tx && F.tx.n_wave_type > 0 && F.tx.wave_type[0] == GSDR_CHIRP) {
                 gsdr_source_chirp(F.d_in, L, (unsigned long long)F.produced, &F.tx_chirp,
                                   F.txi.n_ampl ? F.txi.ampl[0] : 1.f, nullptr);
@@ -183,6 +195,7 @@ static bool run_measurement(const gsdr_command *cmd, int data_fd, int device) {
     }
     for (FrontEnd &F : fe) {
         if (F.dem) gsdr_demod_close(F.dem);
+        if (F.tx_tones) gsdr_txgen_close(F.tx_tones);
         if (F.d_in) (void)hipFree(F.d_in);
         if (F.d_out) (void)hipFree(F.d_out);
         if (F.h_out) (void)hipHostFree(F.h_out);
