@@ -108,6 +108,10 @@ SIGNATURES = [
     ("gsdr_txgen_tones_create", C.c_void_p, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int]),
     ("gsdr_txgen_tones_fill", C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong, C.c_void_p]),
     ("gsdr_txgen_close", None, [C.c_void_p]),
+    ("gsdr_txgen_create", C.c_void_p, [C.POINTER(ParamC), C.POINTER(C.c_float), C.c_int]),
+    ("gsdr_txgen_get", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("gsdr_txgen_get_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("gsdr_txgen_buffer_len", C.c_longlong, [C.c_void_p]),
     ("gsdr_chirp_derive", None, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                  C.POINTER(ChirpParamC)]),
     ("gsdr_command_parse", _vp, [C.c_char_p, C.c_int]),

@@ -1769,6 +1769,13 @@ struct gsdr_txgen {
     int n_tones = 0;
     unsigned *d_fmod = nullptr;
     float2 *d_q0 = nullptr, *d_btab = nullptr, *d_ctab = nullptr;
+    // the TX_buffer_generator state (gsdr_txgen_create)
+    int mode = -1;                     // GSDR_TONES / GSDR_CHIRP, -1: a bare tone comb (gsdr_txgen_tones_create)
+    long long buffer_len = 0;
+    unsigned long long period = 1, last = 0;
+    gsdr_chirp_param cp{};
+    float scale = 1.f;
+    float2 *d_stage = nullptr;         // get() to host memory goes through here
 };
 
 gsdr_txgen *gsdr_txgen_tones_create(int rate, const int *freq, const float *ampl, const float *phase, int n_tones,
@@ -1839,9 +1846,117 @@ void gsdr_txgen_close(gsdr_txgen *g) {
     if (!g) return;
     if (g->device >= 0) (void)hipSetDevice(g->device);
     (void)hipDeviceSynchronize();
-    for (void *p : {(void *)g->d_fmod, (void *)g->d_q0, (void *)g->d_btab, (void *)g->d_ctab})
+    for (void *p : {(void *)g->d_fmod, (void *)g->d_q0, (void *)g->d_btab, (void *)g->d_ctab, (void *)g->d_stage})
         if (p) (void)hipFree(p);
     delete g;
+}
+
+// ref: TX_buffer_generator::TX_buffer_generator, cpp/USRP_buffer_generator.cpp:10-160
+gsdr_txgen *gsdr_txgen_create(const gsdr_param_c *p, const float *ampl, int n_ampl) {
+    g_create_error.clear();
+    auto fail = [](const char *msg) {
+        g_create_error = msg;
+        return (gsdr_txgen *)nullptr;
+    };
+    if (!p) return fail("null parameters");
+    if (p->buffer_len < 1) return fail("buffer_len must be positive");
+    if (p->rate < 1) return fail("rate must be positive");
+    if (p->n_wave_type < 1 || !p->wave_type) return fail("TX buffer generation needs at least one wave_type");
+    const int last = p->wave_type[0];
+    int chirps = 0;
+    bool mixed = false;
+    for (int i = 0; i < p->n_wave_type; ++i) {
+        chirps += p->wave_type[i] == GSDR_CHIRP;
+        mixed |= p->wave_type[i] != last;
+    }
+    if (chirps > 1)      // :26-29
+        return fail("Multiple chirp TX buffer generation has been requested. This feature is not implemented yet.");
+    if (mixed)           // :31-34
+        return fail("Mixed TX buffer generation has been requested. This feature is not implemented yet.");
+    if (last == GSDR_NODSP || last == GSDR_SWONLY) return fail("NODSP CASE NOT IMPLEMENTED.");   // :41-44
+    if (last == GSDR_RAMP || last == GSDR_DIRECT) return fail("RAMP CASE NOT IMPLEMENTED.");      // :46-49
+    if (last == GSDR_NOISE) return fail("NOISE TX generation is empty in the reference (get_from_noise)");   // :52-58
+    gsdr_txgen *g = nullptr;
+    if (last == GSDR_TONES) {
+        const int n = p->n_wave_type;
+        if (p->n_freq < n || !p->freq || n_ampl < n || !ampl) return fail("TONES needs freq[] and ampl[] for every wave_type entry");
+        std::vector<int> tf((size_t)n);
+        std::vector<float> ta((size_t)n);
+        const int nt = gsdr_tx_tone_bins(p->rate, p->freq, ampl, n, tf.data(), ta.data());
+        g = gsdr_txgen_tones_create(p->rate, tf.data(), ta.data(), nullptr, nt > 0 ? nt : 0, p->device_index);
+        if (!g) return nullptr;
+        // TONES_buffer_len: rate, or the multiple of it that holds one buffer (:60-75)
+        g->period = (unsigned long long)p->rate * (unsigned long long)((p->buffer_len + p->rate - 1) / p->rate);
+    } else if (last == GSDR_CHIRP) {
+        if (p->n_freq < 1 || p->n_chirp_f < 1 || p->n_swipe_s < 1 || p->n_chirp_t < 1 || !p->freq || !p->chirp_f ||
+            !p->swipe_s || !p->chirp_t)
+            return fail("CHIRP needs freq[0], chirp_f[0], swipe_s[0] and chirp_t[0]");
+        if (p->device_index >= 0 && hipSetDevice(p->device_index) != hipSuccess)
+            return fail("hipSetDevice failed (no such GPU?)");
+        g = new gsdr_txgen();
+        g->device = p->device_index;
+        g->rate = (unsigned)p->rate;
+        gsdr_chirp_derive(p->rate, p->freq[0], p->chirp_f[0], p->swipe_s[0], p->chirp_t[0], &g->cp);
+        // the TX side also resets num_steps when a step would be shorter than one sample (:111-115); the RX side does not
+        if (p->chirp_t[0] * (float)p->rate / (float)g->cp.num_steps < 1.f)
+            g->cp.num_steps = (unsigned long long)(p->chirp_t[0] * (float)p->rate);
+        if (g->cp.num_steps < 1 || g->cp.length < 1 || g->cp.num_steps > 0x7fffffffffffffffULL / g->cp.length) {
+            delete g;
+            return fail("chirp period overflows");
+        }
+        g->period = g->cp.num_steps * g->cp.length;
+        g->scale = n_ampl > 0 && ampl ? ampl[0] : 1.f;
+    } else {
+        return fail("Void TX generation operation has not been implemented yet!");
+    }
+    g->mode = last;
+    g->buffer_len = p->buffer_len;
+    g->last = 0;
+    return g;
+}
+
+long long gsdr_txgen_buffer_len(const gsdr_txgen *g) { return g ? g->buffer_len : 0; }
+
+// ref: get_from_tones :226-229, get_from_chirp :208-221
+int gsdr_txgen_get_device(gsdr_txgen *g, gsdr_c64 *out_dev, void *hip_stream) {
+    if (!g || !out_dev || g->mode < 0) {
+        g_create_error = "gsdr_txgen_get: bad arguments";
+        return -1;
+    }
+    int rc;
+    if (g->mode == GSDR_TONES) {
+        rc = gsdr_txgen_tones_fill(g, out_dev, g->buffer_len, (long long)(g->last % g->rate), hip_stream);
+    } else {
+        if (g->device >= 0 && hipSetDevice(g->device) != hipSuccess) {
+            g_create_error = "gsdr_txgen_get: hipSetDevice failed";
+            return -1;
+        }
+        rc = gsdr_source_chirp(out_dev, g->buffer_len, g->last, &g->cp, g->scale, hip_stream);
+    }
+    if (rc == 0) g->last = (g->last + (unsigned long long)g->buffer_len) % g->period;
+    return rc;
+}
+
+int gsdr_txgen_get(gsdr_txgen *g, gsdr_c64 *out_host) {
+    if (!g || !out_host || g->mode < 0) {
+        g_create_error = "gsdr_txgen_get: bad arguments";
+        return -1;
+    }
+    if (g->device >= 0 && hipSetDevice(g->device) != hipSuccess) {
+        g_create_error = "gsdr_txgen_get: hipSetDevice failed";
+        return -1;
+    }
+    if (!g->d_stage && dev_alloc(&g->d_stage, (size_t)g->buffer_len) != hipSuccess) {
+        g_create_error = "gsdr_txgen_get: device allocation failed";
+        return -1;
+    }
+    if (gsdr_txgen_get_device(g, reinterpret_cast<gsdr_c64 *>(g->d_stage), nullptr) != 0) return -1;
+    const hipError_t e = hipMemcpy(out_host, g->d_stage, (size_t)g->buffer_len * sizeof(float2), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+        g_create_error = std::string("gsdr_txgen_get: ") + hipGetErrorString(e);
+        return -1;
+    }
+    return 0;
 }
 
 int gsdr_source_chirp(gsdr_c64 *out_dev, long long n, unsigned long long last_index,

@@ -43,83 +43,65 @@ def tone_bins(freq, ampl, rate: int):
 
 
 class TX_buffer_generator:
-    """class TX_buffer_generator, headers/USRP_buffer_generator.hpp.
+    """class TX_buffer_generator, headers/USRP_buffer_generator.hpp -- the Python face of gsdr_txgen_*
+    (include/gsdr.h; include/USRP_buffer_generator.hpp is the C++ one).
 
-    ``get(out)`` fills a torch complex64 CUDA tensor of ``buffer_len`` samples
-    with the next TX buffer; ``close()`` is a no-op kept for symmetry."""
+    ``get(out)`` fills a torch complex64 CUDA tensor (gsdr_txgen_get_device, asynchronous on the current or
+    the given stream) or a numpy complex64 array (gsdr_txgen_get, as the reference's get() to host memory)
+    of ``buffer_len`` samples with the next TX buffer; ``close()`` frees the device tables."""
 
-    def __init__(self, init_parameters: param):
+    def __init__(self, init_parameters: param, device_index: int = 0):
+        import ctypes as C
+        from .demodulator import _carr
         p = self.parameters = init_parameters
         self.buffer_len = int(p.buffer_len)
-        if not p.wave_type:
-            raise GsdrError("TX buffer generation needs at least one wave_type")
-        last = p.wave_type[0]
-        if sum(1 for w in p.wave_type if w == w_type.CHIRP) > 1:
-            raise GsdrError("Multiple chirp TX buffer generation has been requested. "
-                            "This feature is not implemented yet.")
-        if any(w != last for w in p.wave_type):
-            raise GsdrError("Mixed TX buffer generation has been requested. "
-                            "This feature is not implemented yet.")
-        self.mode = w_type(last)
-        if self.mode in (w_type.NODSP, w_type.SWONLY):
-            raise GsdrError("NODSP CASE NOT IMPLEMENTED.")
-        if self.mode in (w_type.RAMP, w_type.DIRECT):
-            raise GsdrError("RAMP CASE NOT IMPLEMENTED.")
-        if self.mode == w_type.NOISE:
-            raise GsdrError("NOISE TX generation is empty in the reference (get_from_noise)")
-        if self.mode == w_type.TONES:
-            n = len(p.wave_type)
-            if len(p.freq) < n or len(p.ampl) < n:
-                raise GsdrError("TONES needs freq[] and ampl[] for every wave_type entry")
-            self._freq, self._ampl = tone_bins(p.freq[:n], p.ampl[:n], int(p.rate))
-            self._phase = np.zeros(len(self._freq), dtype=np.float32)
-            # TONES_buffer_len: rate, or the multiple of it that holds one buffer (:60-75)
-            self._period = int(p.rate) * max(1, -(-self.buffer_len // int(p.rate)))
-            self._last = 0            # TONES_last_sample
-            # the device-side generator (gsdr_txgen_*): tables once, every buffer synthesised on demand
-            import ctypes as C
-            self._tx = None
-            self._device = None
-        else:  # CHIRP
-            cp = chirp_derive(p.rate, p.freq[0], p.chirp_f[0], p.swipe_s[0], p.chirp_t[0])
-            # the TX side also resets num_steps when a step would be shorter than one
-            # sample (cpp/USRP_buffer_generator.cpp:111-115); the RX side does not
-            if np.float32(p.chirp_t[0]) * np.float32(p.rate) / np.float32(cp.num_steps) < 1:
-                cp.num_steps = int(np.float32(p.chirp_t[0]) * np.float32(p.rate))
-            self._cp = cp
-            self._scale = float(p.ampl[0]) if p.ampl else 1.0
-            self._last = 0            # last_index
+        L = self._L = _lib.lib()
+        keep = []
+        pc = _lib.ParamC()
+        pc.rate = int(p.rate)
+        pc.decim = int(p.decim)
+        pc.fft_tones = int(p.fft_tones)
+        pc.pf_average = int(p.pf_average)
+        pc.buffer_len = int(p.buffer_len)
+        a, pc.wave_type = _carr([int(w) for w in p.wave_type], C.c_int); keep.append(a)
+        pc.n_wave_type = len(p.wave_type)
+        a, pc.freq = _carr([int(f) for f in p.freq], C.c_int); keep.append(a)
+        pc.n_freq = len(p.freq)
+        a, pc.chirp_t = _carr([float(f) for f in p.chirp_t], C.c_float); keep.append(a)
+        pc.n_chirp_t = len(p.chirp_t)
+        a, pc.chirp_f = _carr([int(f) for f in p.chirp_f], C.c_int); keep.append(a)
+        pc.n_chirp_f = len(p.chirp_f)
+        a, pc.swipe_s = _carr([int(f) for f in p.swipe_s], C.c_int); keep.append(a)
+        pc.n_swipe_s = len(p.swipe_s)
+        pc.device_index = int(device_index)
+        ampl = np.ascontiguousarray(list(p.ampl) if p.ampl else [], dtype=np.float32)
+        self._h = L.gsdr_txgen_create(C.byref(pc), ampl.ctypes.data_as(C.POINTER(C.c_float)), len(ampl))
+        if not self._h:
+            raise GsdrError(L.gsdr_last_error(None).decode())
+        self.mode = w_type(p.wave_type[0])
 
-    def get(self, out_tensor, stream=None) -> None:
-        if self.mode == w_type.TONES:
-            import ctypes as C
-            import torch
-            assert out_tensor.is_cuda and out_tensor.dtype == torch.complex64 and out_tensor.is_contiguous()
-            L = _lib.lib()
-            if self._tx is None:
-                f = np.ascontiguousarray(self._freq, dtype=np.int32)
-                a = np.ascontiguousarray(self._ampl, dtype=np.float32)
-                ph = np.ascontiguousarray(self._phase, dtype=np.float32)
-                self._device = out_tensor.device
-                self._tx = L.gsdr_txgen_tones_create(int(self.parameters.rate), f.ctypes.data_as(C.POINTER(C.c_int)),
-                                                     a.ctypes.data_as(C.POINTER(C.c_float)), ph.ctypes.data_as(C.POINTER(C.c_float)),
-                                                     len(f), self._device.index if self._device.index is not None else 0)
-                if not self._tx:
-                    raise GsdrError(L.gsdr_last_error(None).decode())
-            if stream is None:
-                stream = torch.cuda.current_stream(out_tensor.device)
-            if L.gsdr_txgen_tones_fill(self._tx, out_tensor.data_ptr(), out_tensor.numel(), int(self._last),
-                                       C.c_void_p(stream.cuda_stream)) != 0:
-                raise GsdrError(L.gsdr_last_error(None).decode())
-            self._last = (self._last + self.buffer_len) % self._period
+    def get(self, out, stream=None) -> None:
+        import ctypes as C
+        if not self._h:
+            raise GsdrError("generator is closed")
+        if isinstance(out, np.ndarray):
+            if out.dtype != np.complex64 or not out.flags.c_contiguous or out.size < self.buffer_len:
+                raise TypeError("need a contiguous complex64 array of buffer_len samples")
+            rc = self._L.gsdr_txgen_get(self._h, out.ctypes.data)
         else:
-            device_chirp(out_tensor, self._last, self._cp, scale=self._scale, stream=stream)
-            self._last = (self._last + self.buffer_len) % (self._cp.num_steps * self._cp.length)
+            import torch
+            if not (out.is_cuda and out.dtype == torch.complex64 and out.is_contiguous() and out.numel() >= self.buffer_len):
+                raise TypeError("need a contiguous complex64 CUDA tensor of buffer_len samples")
+            if stream is None:
+                stream = torch.cuda.current_stream(out.device)
+            rc = self._L.gsdr_txgen_get_device(self._h, out.data_ptr(), C.c_void_p(stream.cuda_stream))
+        if rc != 0:
+            raise GsdrError(self._L.gsdr_last_error(None).decode())
 
     def close(self) -> None:
-        if getattr(self, "_tx", None):
-            _lib.lib().gsdr_txgen_close(self._tx)
-            self._tx = None
+        if getattr(self, "_h", None):
+            self._L.gsdr_txgen_close(self._h)
+            self._h = None
 
     def __del__(self):
         try:

@@ -303,6 +303,19 @@ gsdr_txgen *gsdr_txgen_tones_create(int rate, const int *freq, const float *ampl
                                     int device_index);
 int gsdr_txgen_tones_fill(gsdr_txgen *g, gsdr_c64 *out_dev, long long n, long long start, void *hip_stream);
 void gsdr_txgen_close(gsdr_txgen *g);
+
+/* The reference's TX_buffer_generator as one object (ref: headers/USRP_buffer_generator.hpp:47-66,
+ * cpp/USRP_buffer_generator.cpp:10-160): created from the TX parameters, every get() hands out the next
+ * buffer_len samples.  TONES: the tone comb above (tone set as gsdr_tx_tone_bins(); the sample index wraps at
+ * rate * ceil(buffer_len / rate), :60-75); CHIRP: the chirp_gen law (cpp/kernels.cu:335-372) scaled by ampl[0],
+ * with the TX side's own num_steps reset (:111-115), the running index wrapping at num_steps * length.  Where
+ * the reference exits (mixed or several CHIRP wave types, NODSP/SWONLY/RAMP/DIRECT, NOISE's empty generator)
+ * create returns NULL with the same text in gsdr_last_error(NULL).  gsdr_txgen_get: to host memory
+ * (synchronous, like the reference's get); gsdr_txgen_get_device: to device memory on hip_stream. */
+gsdr_txgen *gsdr_txgen_create(const gsdr_param_c *p, const float *ampl, int n_ampl);
+int gsdr_txgen_get(gsdr_txgen *g, gsdr_c64 *out_host);
+int gsdr_txgen_get_device(gsdr_txgen *g, gsdr_c64 *out_dev, void *hip_stream);
+long long gsdr_txgen_buffer_len(const gsdr_txgen *g);
 /* TX chirp law (ref: chirp_gen, cpp/kernels.cu:335-372) written to device. */
 int gsdr_source_chirp(gsdr_c64 *out_dev, long long n, unsigned long long last_index,
                       const gsdr_chirp_param *cp, float scale, void *hip_stream);

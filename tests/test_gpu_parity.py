@@ -1350,31 +1350,38 @@ def test_tx_tone_generator_against_oracle(cuda_device, gsdr_lib, oracle_mod):
 
 
 def test_tx_tone_generator_at_scale(cuda_device, gsdr_lib):
-    """TX_buffer_generator(TONES) with 2048 and 300 tones at 200 Msps (gsdr_txgen_*: exact phase once per tone
-    and 1024 samples, two table factors for the rest) against the per-sample synthesis of the input source
-    (one float sincos of an exact integer phase per tone and sample), buffer by buffer across the wrap of the
-    sample index at `rate`; and a buffer length that is no multiple of 1024."""
+    """TX_buffer_generator(TONES) with 2048 tones at 200 Msps and 300 tones at 1 Msps (gsdr_txgen_*: exact
+    phase once per tone and 1024 samples, two table factors for the rest) against the per-sample synthesis of
+    the input source (one float sincos of an exact integer phase per tone and sample), buffer by buffer --
+    the second case across the wrap of the sample index at `rate`, with a buffer length that is no multiple
+    of 1024, and into host memory on alternate buffers (gsdr_txgen_get)."""
     import torch
     import gpu_sdr_amd as g
+    from gpu_sdr_amd.generator import tone_bins
     from gpu_sdr_amd.source import device_tones, tone_comb
-    rate = 200_000_000
-    for N, L, nbuf in [(2048, 150_000, 3), (300, 99_999, 4)]:
+    for N, rate, L, nbuf in [(2048, 200_000_000, 150_000, 3), (300, 1_000_000, 99_999, 13)]:
         freq, ampl, phase = tone_comb(N, rate, 17)
         tx = g.TX_buffer_generator(g.param(mode="TX", rate=rate, buffer_len=L, freq=[int(f) for f in freq],
                                            ampl=[float(a) for a in ampl], wave_type=[g.w_type.TONES] * N))
-        tx._last = rate - L - 1234          # the third buffer straddles the wrap at `rate`
-        from gpu_sdr_amd.generator import tone_bins
         f2, a2 = tone_bins(freq, ampl, rate)
         x = torch.empty(L, dtype=torch.complex64, device=cuda_device)
+        xh = np.empty(L, dtype=np.complex64)
         want = torch.empty(L, dtype=torch.complex64, device=cuda_device)
+        period = rate * max(1, -(-L // rate))
+        start = 0
         for c in range(nbuf):
-            start = tx._last
-            tx.get(x)
+            if c % 2:
+                tx.get(xh)
+                got = torch.from_numpy(xh).to(cuda_device)
+            else:
+                tx.get(x)
+                got = x
             device_tones(want, start, rate, f2, a2, np.zeros(len(f2), dtype=np.float32), sigma=0.0)
             torch.cuda.synchronize()
-            err = float((x - want).abs().max())
+            err = float((got - want).abs().max())
             record_margin(err / float(np.sum(a2)), "max abs error / sum of amplitudes")
             assert err <= 2e-6 * float(np.sum(a2)), (N, c, err)
+            start = (start + L) % period
         tx.close()
 
 

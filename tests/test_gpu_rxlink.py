@@ -108,3 +108,39 @@ def test_rx_link_first_calls_are_not_late(cuda_device, gsdr_lib):
     assert info["worst_ms"] < 10.0, info
     assert info["calls_above_3ms"] <= 1, info        # (the first-use costs were three calls of 5 - 7 ms)
     assert info["worst_ms_after_first_8_calls"] < 5.0, info
+
+
+def run_tx(tmp_path, cfg_lines, nbuf):
+    cfg, fout = tmp_path / "txcfg.txt", tmp_path / "tx.c64"
+    cfg.write_text("\n".join(cfg_lines) + "\n")
+    p = subprocess.run([RX_LINK, "tx", str(cfg), str(fout), str(nbuf)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    return json.loads(p.stdout.strip().splitlines()[-1]), np.fromfile(fout, dtype=np.complex64)
+
+
+def test_tx_class_tones_and_chirp_against_oracle(cuda_device, gsdr_lib, oracle_mod, tmp_path):
+    """`new TX_buffer_generator(&param)` + get() from include/USRP_buffer_generator.hpp (the reference's TX
+    class, over gsdr_txgen_*), to host memory, buffer by buffer: the tone comb against the oracle's tone_gen
+    (bin assignment quirks included, buffers wrapping the period) and the chirp against its chirp_gen."""
+    rate, L, nbuf = 1_000_000, 300_007, 5
+    freq = [1000, -250_000, 0, 77_777, 1000, -rate, rate, rate // 2, -5, -1]
+    ampl = [0.1, 0.2, 0.3, 0.05, 0.4, 0.07, 0.9, 0.11, 0.6, 0.02]
+    info, y = run_tx(tmp_path, ["mode TONES", f"rate {rate}", f"buffer_len {L}", "freq " + " ".join(map(str, freq)),
+                                "ampl " + " ".join(map(str, ampl))], nbuf)
+    assert info["buffers"] == nbuf and y.size == nbuf * L
+    start = 0
+    for c in range(nbuf):
+        want = oracle_mod.tone_gen(freq, ampl, rate, start, L)
+        err = float(np.max(np.abs(y[c * L:(c + 1) * L] - want)))
+        record_margin(err / float(np.sum(ampl)), "tones: max abs error / sum of amplitudes")
+        assert err <= 2e-6 * float(np.sum(ampl)), (c, err)
+        start = (start + L) % rate
+    rate, L, nbuf, steps, t = 200_000_000, 100_000, 4, 10_000, 0.0075
+    info, y = run_tx(tmp_path, ["mode CHIRP", f"rate {rate}", f"buffer_len {L}", "freq -80000000", "chirp_f 80000000",
+                                f"swipe_s {steps}", f"chirp_t {t}", "ampl 0.25"], nbuf)
+    cp = oracle_mod.chirp_params(rate, -80_000_000, 80_000_000, steps, t)
+    last = 0
+    for c in range(nbuf):
+        want = oracle_mod.chirp_gen(cp, last, L, 0.25)
+        np.testing.assert_allclose(y[c * L:(c + 1) * L], want, rtol=0, atol=3e-7)
+        last = (last + L) % (cp.num_steps * cp.length)

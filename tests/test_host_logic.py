@@ -34,6 +34,13 @@ def test_cpp_shim_header_compiles_with_gxx(tmp_path):
                    " return sizeof(RX_buffer_demodulator) > 0 ? 0 : 1; }\n")
     import subprocess
     subprocess.check_call(["g++", "-std=c++11", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)])
+    # and the TX side: include/USRP_buffer_generator.hpp (class TX_buffer_generator)
+    src2 = tmp_path / "t2.cpp"
+    src2.write_text('#include "USRP_buffer_generator.hpp"\n'
+                    "int main(){ param p; p.buffer_len = 100; p.rate = 1000; p.wave_type.push_back(TONES);\n"
+                    " p.freq.push_back(10); p.ampl.push_back(0.5f);\n"
+                    " return sizeof(TX_buffer_generator) > 0 ? 0 : 1; }\n")
+    subprocess.check_call(["g++", "-std=c++11", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src2)])
 
 
 def test_c_header_is_plain_c(tmp_path):

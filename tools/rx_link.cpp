@@ -43,6 +43,7 @@
 #include <vector>
 
 #include "USRP_demodulator.hpp"
+#include "USRP_buffer_generator.hpp"
 
 template <typename T>
 class BlockingQueue {  // stands in for the boost::lockfree queues of the reference
@@ -73,6 +74,60 @@ static w_type wave_from_string(const std::string &s) {
 }
 
 // rx_single_link over a recorded stream; see the header comment
+// rx_link tx <config.txt> <out.c64> <n_buffers>: `new TX_buffer_generator(&param)` + get(), the loop of the
+// reference's TX side (ref: cpp/USRP_server_link_threads.cpp, tx_single_link), written to a file
+static int tx_mode(int argc, char **argv) {
+    if (argc < 5) {
+        std::fprintf(stderr, "usage: rx_link tx <config.txt> <out.c64> <n_buffers>\n");
+        return 2;
+    }
+    param p;
+    p.mode = TX;
+    p.rate = 0; p.gain = 0; p.bw = 0; p.tone = 0; p.samples = 0; p.delay = 0; p.burst_on = p.burst_off = 0;
+    p.buffer_len = 0; p.tuning_mode = false; p.decim = 0; p.data_mem_mult = 1; p.fft_tones = 0; p.pf_average = 4;
+    w_type mode = NODSP;
+    int channels = -1;
+    std::ifstream cfg(argv[2]);
+    if (!cfg) { std::fprintf(stderr, "cannot read %s\n", argv[2]); return 2; }
+    std::string line;
+    while (std::getline(cfg, line)) {
+        std::istringstream is(line);
+        std::string key;
+        if (!(is >> key)) continue;
+        if (key == "mode") { std::string m; is >> m; mode = wave_from_string(m); }
+        else if (key == "channels") is >> channels;
+        else if (key == "rate") is >> p.rate;
+        else if (key == "buffer_len") is >> p.buffer_len;
+        else if (key == "freq") { int v; while (is >> v) p.freq.push_back(v); }
+        else if (key == "ampl") { float v; while (is >> v) p.ampl.push_back(v); }
+        else if (key == "chirp_f") { int v; while (is >> v) p.chirp_f.push_back(v); }
+        else if (key == "swipe_s") { int v; while (is >> v) p.swipe_s.push_back(v); }
+        else if (key == "chirp_t") { float v; while (is >> v) p.chirp_t.push_back(v); }
+    }
+    if (channels < 0) channels = mode == CHIRP ? 1 : (int)p.freq.size();
+    for (int k = 0; k < channels; ++k) p.wave_type.push_back(mode);
+    const long long n_buffers = std::atoll(argv[4]);
+    FILE *fout = std::fopen(argv[3], "wb");
+    if (!fout || p.buffer_len == 0) { std::fprintf(stderr, "cannot open the output file\n"); return 2; }
+    RX_buffer_demodulator::device_index() = 0;
+    TX_buffer_generator *generator = new TX_buffer_generator(&p);
+    float2 *buf = nullptr;
+    if (hipHostMalloc((void **)&buf, p.buffer_len * sizeof(float2)) != hipSuccess) return 1;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (long long k = 0; k < n_buffers; ++k) {
+        generator->get(&buf);
+        std::fwrite(buf, sizeof(float2), p.buffer_len, fout);
+    }
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    generator->close();
+    delete generator;
+    std::fclose(fout);
+    (void)hipHostFree(buf);
+    std::printf("{\"harness\": \"tx_single_link\", \"buffers\": %lld, \"buffer_len\": %d, \"msamples_per_s_incl_file\": %.1f}\n",
+                n_buffers, (int)p.buffer_len, (double)n_buffers * (double)p.buffer_len / sec / 1e6);
+    return 0;
+}
+
 static int file_mode(int argc, char **argv) {
     if (argc < 5) {
         std::fprintf(stderr, "usage: rx_link file <config.txt> <in.c64> <out.c64> [pipe]\n");
@@ -164,6 +219,7 @@ static int file_mode(int argc, char **argv) {
 
 int main(int argc, char **argv) {
     if (argc > 1 && std::string(argv[1]) == "file") return file_mode(argc, argv);
+    if (argc > 1 && std::string(argv[1]) == "tx") return tx_mode(argc, argv);
     const int n_tones = argc > 1 ? std::atoi(argv[1]) : 256;
     const int decim = argc > 2 ? std::atoi(argv[2]) : 100;
     const int n_buffers = argc > 3 ? std::atoi(argv[3]) : 200;
