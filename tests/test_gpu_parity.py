@@ -1470,7 +1470,8 @@ def test_describe_reports_the_engine_that_ran(cuda_device, gsdr_lib, monkeypatch
 def test_two_front_ends_on_one_gpu_do_not_disturb_each_other(cuda_device, gsdr_lib):
     """The reference runs one demodulator per RX front-end, each on its own thread (A_RX2 and B_RX2 of one
     board share the GPU).  A heavy matrix-core DIRECT handle streams on one thread while TONES (in-LDS FFT),
-    the undecimated mix, the chirp lock-in and a second DIRECT handle run on threads and streams of their own; every result of the
+    the undecimated mix, the chirp lock-in, a second DIRECT handle and the TX tone comb generator run on threads and
+    streams of their own; every result of the
     small handles must be bit-identical to what the same handle produces on an idle GPU.
 
     What this guards: rule R3 of DESIGN.md section 4.1 holds ACROSS kernels -- a kernel in which the compiler
@@ -1503,7 +1504,22 @@ def test_two_front_ends_on_one_gpu_do_not_disturb_each_other(cuda_device, gsdr_l
     def mk_direct():                                   # a second matrix-core front-end
         return make_direct(direct_freq, rate, 100, 4, L)
 
-    cases = {"chirp": mk_chirp, "tones": mk_tones, "mix": mk_mix, "direct": mk_direct}
+    class TxAsDem:
+        """the TX tone comb generator behind the demodulators' calling convention: TX and RX of a
+        front-end run at the same time"""
+        def __init__(self):
+            self.gen = g.TX_buffer_generator(g.param(mode="TX", rate=rate, buffer_len=L, freq=[int(f) for f in tone_freq],
+                                                     ampl=[0.01] * len(tone_freq), wave_type=[g.w_type.TONES] * len(tone_freq)))
+            self.out_capacity = L
+
+        def process_device(self, x, out, stream=None):
+            self.gen.get(out, stream)
+            return L
+
+        def close(self):
+            self.gen.close()
+
+    cases = {"chirp": mk_chirp, "tones": mk_tones, "mix": mk_mix, "direct": mk_direct, "tx": TxAsDem}
     xs = [torch.from_numpy(crandn(rng, L)).to(cuda_device) for _ in range(4)]
     refs = {}
     for name, mk in cases.items():
