@@ -86,7 +86,7 @@ struct MfmaShape {
     double inv_rate;
     unsigned m_mod_rate;
     unsigned idx_base;         // NCO index of sample woff*M (mod rate)
-    int slot_cur, slot_prev;   // absmax slots of this and the previous buffer
+    int seg_k;                 // blocks of M samples per segment of the maxima table (segment = seg_k * M samples)
     float unscale;             // power of two the taps were divided by
     int rt;                    // ring kernel: row tiles a workgroup does one after the other (0, 1: one)
     int timing_mode;           // GSDR_MFMA_TIMING (wrong results): 1 = no stores, 2 = one block only, 3 = both
@@ -101,7 +101,7 @@ struct MfmaLaunch {
     const float2 *ptab;        // [ceil(nk8/KS)][NT32*32]  w_n^(hi*PK)
     const float2 *dtab;        // [32][NT32*32]            w_n^(row*M)
     const unsigned *fmod;      // [NT32*32]
-    const unsigned *maxbits;   // [slots][kAbsmaxPartials] absmax slots (partial maxima of the staging pass)
+    const unsigned *segmax;    // this call's table of segment maxima (float bits) over [carry | buffer], see absmax_kernel
     float2 *out;
     const uint4 *img;          // AsmRing16P: [ngt][nhi] pre-converted ring-slot images of 8 KiB (ddc_convert_kernel)
     MfmaShape sh;
@@ -118,12 +118,31 @@ void mfma_build_tables(const MfmaPlan &pl, const std::vector<unsigned> &fmod_in,
                        std::vector<uint4> &bfrag, std::vector<float2> &ptab,
                        std::vector<float2> &dtab, std::vector<float> &taps,
                        std::vector<unsigned> &fmod, float &unscale);
-// partial maxima per absmax slot (the workgroups of the staging pass fold theirs into them)
-constexpr int kAbsmaxPartials = 128;
-hipError_t launch_absmax(const float2 *x, long long n, unsigned *slots, int cur, int next,
-                         float2 *head_cur, long long head_n, float2 *head_next, int carry_len,
-                         float2 *tail, long long tail0, hipStream_t st, const float2 *extra_src = nullptr,
-                         float2 *extra_dst = nullptr, long long extra_n = 0);
+// The staging pass in front of the matrix-core kernels.  The logical stream of a call is T = [B | A]: A the new
+// buffer x[0 .. n), B what the previous call left in front of it (DIRECT: the raw-sample carry, read from the head
+// copy the previous pass wrote; TONES: the unconsumed end of the previous raw window, copied to b_dst).  One pass
+//   * folds max |finite component| of every segment T[q*seg_len, (q+1)*seg_len) into seg[q] (float bits,
+//     atomicMax on a table the previous pass cleared; NaN and Inf patterns are left out: they must not set the
+//     scale of the ordinary samples around them) and clears seg_clear[0 .. nseg_alloc) for the next call;
+//   * lays out the copies the main kernels read without boundary cases: head_cur[carry_len + i] = x[i], i < head_n;
+//     head_next[i - (n - carry_len)] = x[i] for the last carry_len samples; tail[i - tail0] = x[i], i >= tail0.
+struct StageLaunch {
+    const float2 *x;           // A
+    long long n;
+    const float2 *b;           // B (may be null when nb == 0)
+    long long nb;
+    float2 *b_dst;             // copy of B (TONES), or null
+    unsigned *seg, *seg_clear;
+    int nseg_alloc;            // entries of a table
+    long long seg_len;         // samples per segment
+    float2 *head_cur;
+    long long head_n;
+    float2 *head_next;
+    int carry_len;
+    float2 *tail;
+    long long tail0;
+};
+hipError_t launch_absmax(const StageLaunch &s, hipStream_t st);
 // AsmRing16 / AsmRing16P / AsmRing16W8: assembly main loops on the 16x16x32 MFMA (production, pre-converted
 // operands, eight-wave workgroups); AsmRing: round 1's loop on the 32x32x16 MFMA; Cxx: compiler-scheduled
 // (TT, PK, W apply to it only; the assembly kernels are TT = 1, PK = 32, W = 4).

@@ -64,13 +64,20 @@ struct Frag {
     half8 hi, lo;
 };
 
+// x * h with 0 * anything = 0 (padded taps meet samples outside the window, which may be anything)
+__device__ __forceinline__ float mul_legacy(float x, float h) {
+    float r;
+    asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(h));
+    return r;
+}
+
 // one complex sample times its (scaled) tap, split into fp16 hi and lo
 __device__ __forceinline__ void split_pair(float xr, float xi, float hs, half2v &hi, half2v &lo) {
     // no contraction: the residual is (rounded product) - hi, bit for bit what the assembly loops
-    // compute (v_mul_f32, v_cvt_pk_f16_f32, v_fma_mix_f32 x*1.0 - hi), so that a stream may change
+    // compute (v_mul_legacy_f32, v_cvt_pk_f16_f32, v_fma_mix_f32 x*1.0 - hi), so that a stream may change
     // between the kernels that convert in the loop and the pre-converted path from call to call
 #pragma clang fp contract(off)
-    const float2v v = {xr * hs, xi * hs};
+    const float2v v = {mul_legacy(xr, hs), mul_legacy(xi, hs)};
     hi = __builtin_convertvector(v, half2v);
     const float2v res = v - __builtin_convertvector(hi, float2v);
     lo = __builtin_convertvector(res, half2v);
@@ -142,13 +149,7 @@ __device__ __forceinline__ void stamp(int slot) {
 __device__ __forceinline__ void stamp(int) {}
 #endif
 
-// max |component| over this and the previous buffer.  absmax_kernel folds the maxima of its workgroups
-// into the kAbsmaxPartials addresses of its slot (float bits of non-negative numbers order like
-// unsigned integers) with atomicMax, at most four workgroups per address: same-address atomics
-// serialise at ~100 ns each -- with 16 addresses they cost the pass 1.6 us of its 6, a single address
-// would cost 25 (tools/ubench_read.hip).  Every wave reduces the two slots for itself: one 8-byte
-// load per lane and slot (a wider slot costs registers the assembly kernels do not have: the
-// pre-converted-operand kernel dropped to one wave per SIMD with 512 partials), then a DPP butterfly.
+// Wave-wide maximum of unsigned values (DPP butterfly; every lane gets the result).
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
     int x = (int)v;
 #define GSDR_DPP_MAX(ctrl, row_mask)                                                          \
@@ -166,16 +167,35 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
     return (unsigned)__builtin_amdgcn_readlane(x, 63);
 }
 
-__device__ __forceinline__ unsigned slot_max(const unsigned *slots, int cur, int prev) {
-    static_assert(kAbsmaxPartials == 128, "one 8-byte load per lane and slot");
-    unsigned tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));
-    const int lane = (int)(tid & 63u);
-    const uint2 a = reinterpret_cast<const uint2 *>(slots + (size_t)cur * kAbsmaxPartials)[lane];
-    const uint2 b = reinterpret_cast<const uint2 *>(slots + (size_t)prev * kAbsmaxPartials)[lane];
-    const unsigned u = a.x > a.y ? a.x : a.y, w = b.x > b.y ? b.x : b.y;
-    return wave_max_u32(u > w ? u : w);
+// The scale of ONE OUTPUT ROW (round 3; rounds 1 and 2 had one scale per buffer).  Row o of a launch reads
+// T[o*M, o*M + M*F) of the call's logical stream T = [carry | buffer] (TONES: the raw window); absmax_kernel
+// left max |finite component| of every segment of seg_k*M samples of T in a.segmax.  The exponent that puts
+// the row's largest |x * h'| below 2^14 (fp16 holds 2^16, |h'| <= 1):  |x| < 2^(e-126)  =>  se = 140 - e.
+// So what a row's ordinary samples keep of their 22 bits depends on the samples of ITS window alone, as the
+// precision of an output of the reference depends on its window alone (ref: cpp/kernels.cu:82-83 is
+// elementwise, cpp/fir.cu:48-61 sums one window): a spike, however large, costs the rows that hold it
+// nothing relative to their own magnitude and the other rows nothing at all, and a NaN or Inf (left out of
+// the maxima) turns into NaN exactly in the rows whose window holds it (x * h' * S overflows or stays NaN
+// in the conversion; zero-padded taps multiply with v_mul_legacy_f32, where 0 * anything = 0).
+// All kernels derive the same exponent from the same table: a stream may change kernels from call to call.
+__device__ __forceinline__ int row_scale_exp(const MfmaLaunch &a, int o) {
+    const MfmaShape &sh = a.sh;
+    const int oc = o < sh.nout ? o : sh.nout - 1;
+    const int F = sh.MF / sh.M;
+    int q0 = oc, q1 = oc + F - 1;
+    if (sh.seg_k > 1) {
+        q0 /= sh.seg_k;
+        q1 /= sh.seg_k;
+    }
+    unsigned m = 0;
+    for (int q = q0; q <= q1; ++q) {
+        const unsigned v = a.segmax[q];
+        m = m > v ? m : v;
+    }
+    int se = 140 - (int)((m >> 23) & 0xffu);
+    return se > 100 ? 100 : (se < -100 ? -100 : se);
 }
+__device__ __forceinline__ float exp2_bits(int e) { return __builtin_bit_cast(float, (unsigned)(127 + e) << 23); }
 
 // w_n^(idx_base + 32*gt*M): the phasor of tone n (fm = f_n mod rate) at the first row of
 // row tile gt.  Computed behind the loop, in the shadow of the dtab loads (as an operand of the
@@ -195,8 +215,9 @@ __device__ __forceinline__ float2 tile_phasor(const MfmaLaunch &a, int gt, unsig
 // guard of the stores the compiler emits sixteen load -> wait -> store round trips, one after the
 // other (4.5 us of a 20 us workgroup on C2, scratch/stamp_c2_phases.sh).  The tables are padded to
 // whole tiles, so the loads need no guard.
-__device__ __forceinline__ void store_tile(const MfmaLaunch &a, int gt, int n, int hh, float invS,
+__device__ __forceinline__ void store_tile(const MfmaLaunch &a, int gt, int n, int hh, int se_self,
                                            const float16v &accr, const float16v &acci) {
+    // se_self: the scale exponent of row (lane & 31) of this tile (row_scale_exp); a lane holds 16 rows
     const MfmaShape &sh = a.sh;
     const int Np = sh.NT32 * 32;
     const unsigned fm = a.fmod[n];
@@ -205,11 +226,13 @@ __device__ __forceinline__ void store_tile(const MfmaLaunch &a, int gt, int n, i
     for (int i = 0; i < 16; ++i) d[i] = a.dtab[(size_t)((i & 3) + 8 * (i >> 2) + 4 * hh) * Np + n];
     asm volatile("" ::: "memory");          // the loads stay above the phasor arithmetic
     const float2 base = tile_phasor(a, gt, fm);
-    const float br = base.x * invS, bi = base.y * invS;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
-        const float rr = br * d[i].x - bi * d[i].y, ri = br * d[i].y + bi * d[i].x;
+        const int se = __builtin_amdgcn_ds_bpermute(row << 2, se_self);
+        const float inv = exp2_bits(-se) * sh.unscale;
+        const float dx = d[i].x * inv, dy = d[i].y * inv;
+        const float rr = base.x * dx - base.y * dy, ri = base.x * dy + base.y * dx;
         float2 y;
         y.x = accr[i] * rr - acci[i] * ri;
         y.y = accr[i] * ri + acci[i] * rr;
@@ -219,12 +242,12 @@ __device__ __forceinline__ void store_tile(const MfmaLaunch &a, int gt, int n, i
 }
 
 template <int TT>
-__device__ __forceinline__ void store_rows(const MfmaLaunch &a, int gt, int n0, int hh, float invS,
+__device__ __forceinline__ void store_rows(const MfmaLaunch &a, int gt, int n0, int hh, int se_self,
                                            const float16v (&accr)[TT], const float16v (&acci)[TT]) {
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) {
         const int n = n0 + tt * 32;
-        store_tile(a, gt, n, hh, invS, accr[tt], acci[tt]);
+        store_tile(a, gt, n, hh, se_self, accr[tt], acci[tt]);
     }
 }
 
@@ -290,15 +313,10 @@ __global__ __launch_bounds__(64 * W, TT == 1 ? 2 : 1) void ddc_mfma_kernel(const
                     Bf[tt][ks][c][sp] = __builtin_bit_cast(half8, v);
                 }
 
-    // ---- scale from the absmax pass ----
-    const unsigned mb = slot_max(a.maxbits, sh.slot_cur, sh.slot_prev);
-    int se = 140 - (int)((mb >> 23) & 0xffu);       // |x| < 2^(e-126), |h'| <= 1  =>  |b| < 2^14
-    se = se > 100 ? 100 : (se < -100 ? -100 : se);
-    const float S = bits_to_float((unsigned)(127 + se) << 23);
-    const float invS = bits_to_float((unsigned)(127 - se) << 23) * sh.unscale;
-
-    // ---- this lane's row of the A operand ----
+    // ---- this lane's row of the A operand and its scale (row_scale_exp) ----
     const int o = gt * 32 + r;
+    const int se = row_scale_exp(a, o);
+    const float S = exp2_bits(se);
     const int oc = o < sh.nout ? o : sh.nout - 1;
     // head: sample s lives at head[s + carry_len]; tail: at tail[s - tail0]
     const float2 *xbase = gt == 0 ? a.head + sh.carry_len
@@ -389,7 +407,7 @@ __global__ __launch_bounds__(64 * W, TT == 1 ? 2 : 1) void ddc_mfma_kernel(const
         __builtin_amdgcn_sched_barrier(0);
     }
     if (!active) return;
-    store_rows<TT>(a, gt, n0, hh, invS, accr, acci);
+    store_rows<TT>(a, gt, n0, hh, se, accr, acci);
 }
 
 // Variant with the converted A operand shared through an LDS ring
@@ -399,7 +417,7 @@ __global__ __launch_bounds__(64 * W, TT == 1 ? 2 : 1) void ddc_mfma_kernel(const
 // One row tile of ddc_mfma_ring_kernel: the assembly loop and the stores.  `first`: load the
 // phasor images (the second tile of a workgroup keeps them).
 __device__ __forceinline__ __attribute__((target("no-packed-fp32-ops"))) void ring_tile(
-    const MfmaLaunch &a, uint4 *lds, int gt, int first, int se, int tg, int wave, bool active) {
+    const MfmaLaunch &a, uint4 *lds, int gt, int first, int tg, int wave, bool active) {
     constexpr int KS = 4;
     const MfmaShape &sh = a.sh;
     const int Np = sh.NT32 * 32;
@@ -411,7 +429,7 @@ __device__ __forceinline__ __attribute__((target("no-packed-fp32-ops"))) void ri
     asm volatile("" : "+v"(tid));
     const int lane = (int)(tid & 63u);
     const int r = lane & 31, hh = lane >> 5;
-    const float S = bits_to_float((unsigned)(127 + se) << 23);
+    const float S = exp2_bits(row_scale_exp(a, gt * 32 + r));   // this lane converts row r of the tile
     const unsigned to = (unsigned)((4 * hh + 8 * wave) * 4);
     const int n0 = tg * 32 + r;
     const unsigned po = (unsigned)n0 * 8u;
@@ -459,7 +477,7 @@ __device__ __forceinline__ __attribute__((target("no-packed-fp32-ops"))) void ri
         unsigned tid2 = threadIdx.x;
         asm volatile("" : "+v"(tid2));
         const int lane2 = (int)(tid2 & 63u);
-        const float invS = bits_to_float((unsigned)(127 - se) << 23) * sh.unscale;
+        const int se_self = row_scale_exp(a, gt * 32 + (lane2 & 31));   // again: nothing lives across the assembly
         float16v accr, acci;
         const float4v *acc = reinterpret_cast<const float4v *>(lds) + wave * 512 + lane2;
 #pragma unroll
@@ -472,7 +490,7 @@ __device__ __forceinline__ __attribute__((target("no-packed-fp32-ops"))) void ri
             }
         }
         const int n = tg * 32 + (lane2 & 31);
-        store_tile(a, gt, n, lane2 >> 5, invS, accr, acci);
+        store_tile(a, gt, n, lane2 >> 5, se_self, accr, acci);
     }
 }
 
@@ -496,16 +514,13 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
     const int tg_raw = (q % sh.ntq) * W + wave;
     const bool active = tg_raw < sh.ntg;
     const int tg = active ? tg_raw : sh.ntg - 1;
-    const unsigned mb = slot_max(a.maxbits, sh.slot_cur, sh.slot_prev);
-    int se = 140 - (int)((mb >> 23) & 0xffu);
-    se = se > 100 ? 100 : (se < -100 ? -100 : se);
     stamp(0);
     stamp(2);
-    ring_tile(a, lds, gt0, 1, se, tg, wave, active);
+    ring_tile(a, lds, gt0, 1, tg, wave, active);
     if (rt > 1 && gt0 + 8 < sh.ngt) {
         // the ring of the next tile overlays the accumulators of this one: every wave has read its own
         workgroup_sync();
-        ring_tile(a, lds, gt0 + 8, 0, se, tg, wave, active);
+        ring_tile(a, lds, gt0 + 8, 0, tg, wave, active);
     }
     stamp(1);
 }
@@ -520,7 +535,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
 //                                                   tone 16*th + (l & 15) of the wave's 32.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ __attribute__((target("no-packed-fp32-ops"))) void store_tile16(
-    const MfmaLaunch &a, int gt, int tg, int lane, float invS, const float16v &accr, const float16v &acci) {
+    const MfmaLaunch &a, int gt, int tg, int lane, int se_self, const float16v &accr, const float16v &acci) {
     const MfmaShape &sh = a.sh;
     const int Np = sh.NT32 * 32;
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -542,7 +557,6 @@ __device__ __forceinline__ __attribute__((target("no-packed-fp32-ops"))) void st
         const int src = (16 * th + l15) << 2;
         const float bx = bits_to_float((unsigned)__builtin_amdgcn_ds_bpermute(src, (int)float_to_bits(base_self.x)));
         const float by = bits_to_float((unsigned)__builtin_amdgcn_ds_bpermute(src, (int)float_to_bits(base_self.y)));
-        const float br = bx * invS, bi = by * invS;
         const int n = tg * 32 + 16 * th + l15;
 #pragma unroll
         for (int rh = 0; rh < 2; ++rh)
@@ -550,7 +564,10 @@ __device__ __forceinline__ __attribute__((target("no-packed-fp32-ops"))) void st
             for (int j = 0; j < 4; ++j) {
                 const int i = 4 * (2 * rh + th) + j;
                 const int row = 16 * rh + 4 * l4 + j;
-                const float rr = br * d[i].x - bi * d[i].y, ri = br * d[i].y + bi * d[i].x;
+                // 1 / S of this row (se_self: the exponent of row lane & 31, see row_scale_exp)
+                const float inv = exp2_bits(-__builtin_amdgcn_ds_bpermute(row << 2, se_self)) * sh.unscale;
+                const float dx = d[i].x * inv, dy = d[i].y * inv;
+                const float rr = bx * dx - by * dy, ri = bx * dy + by * dx;
                 float2 y;
                 y.x = accr[i] * rr - acci[i] * ri;
                 y.y = accr[i] * ri + acci[i] * rr;
@@ -561,7 +578,7 @@ __device__ __forceinline__ __attribute__((target("no-packed-fp32-ops"))) void st
 }
 
 __device__ __forceinline__ __attribute__((target("no-packed-fp32-ops"))) void ring16_tile(
-    const MfmaLaunch &a, uint4 *lds, int gt, int first, int se, int tg, int wave, bool active) {
+    const MfmaLaunch &a, uint4 *lds, int gt, int first, int tg, int wave, bool active) {
     constexpr int KS = 4;
     const MfmaShape &sh = a.sh;
     const int Np = sh.NT32 * 32;
@@ -570,7 +587,7 @@ __device__ __forceinline__ __attribute__((target("no-packed-fp32-ops"))) void ri
     asm volatile("" : "+v"(tid));
     const int lane = (int)(tid & 63u);
     const int r = lane & 31, hh = lane >> 5;
-    const float S = bits_to_float((unsigned)(127 + se) << 23);
+    const float S = exp2_bits(row_scale_exp(a, gt * 32 + r));   // this lane converts row r of the tile
     const unsigned to = (unsigned)((4 * hh + 8 * wave) * 4);
     // P of the lane's two tones: tone 16*th + (lane & 15); the second one 16 tones = 128 bytes on
     const unsigned po = (unsigned)(tg * 32 + (lane & 15)) * 8u;
@@ -622,7 +639,7 @@ __device__ __forceinline__ __attribute__((target("no-packed-fp32-ops"))) void ri
         unsigned tid2 = threadIdx.x;
         asm volatile("" : "+v"(tid2));
         const int lane2 = (int)(tid2 & 63u);
-        const float invS = bits_to_float((unsigned)(127 - se) << 23) * sh.unscale;
+        const int se_self = row_scale_exp(a, gt * 32 + (lane2 & 31));   // again: nothing lives across the assembly
         float16v accr, acci;
         const float4v *acc = reinterpret_cast<const float4v *>(lds) + wave * 512 + lane2;
 #pragma unroll
@@ -634,7 +651,7 @@ __device__ __forceinline__ __attribute__((target("no-packed-fp32-ops"))) void ri
                 acci[qd * 4 + j] = vi[j];
             }
         }
-        store_tile16(a, gt, tg, lane2, invS, accr, acci);
+        store_tile16(a, gt, tg, lane2, se_self, accr, acci);
     }
 }
 
@@ -654,13 +671,10 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
     const int tg = active ? tg_raw : sh.ntg - 1;
     stamp(0);
     stamp(2);
-    const unsigned mb = slot_max(a.maxbits, sh.slot_cur, sh.slot_prev);
-    int se = 140 - (int)((mb >> 23) & 0xffu);
-    se = se > 100 ? 100 : (se < -100 ? -100 : se);
-    ring16_tile(a, lds, gt0, 1, se, tg, wave, active);
+    ring16_tile(a, lds, gt0, 1, tg, wave, active);
     if (rt > 1 && gt0 + 8 < sh.ngt) {
         workgroup_sync();
-        ring16_tile(a, lds, gt0 + 8, 0, se, tg, wave, active);
+        ring16_tile(a, lds, gt0 + 8, 0, tg, wave, active);
     }
     stamp(1);
 }
@@ -697,9 +711,6 @@ __global__ __launch_bounds__(512, 2) __attribute__((target("no-packed-fp32-ops")
     const int tg_raw = (q % ntq8) * W + wave;
     const bool active = tg_raw < sh.ntg;      // idle waves still convert and keep the barriers
     const int tg = active ? tg_raw : sh.ntg - 1;
-    const unsigned mb = slot_max(a.maxbits, sh.slot_cur, sh.slot_prev);
-    int se = 140 - (int)((mb >> 23) & 0xffu);
-    se = se > 100 ? 100 : (se < -100 ? -100 : se);
     const int Np = sh.NT32 * 32;
     const int nhi = timing_one_block(sh) ? 1 : (sh.nk8 + KS - 1) / KS;
     unsigned tid = threadIdx.x;
@@ -707,7 +718,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((target("no-packed-fp32-ops")
     const int lane = (int)(tid & 63u);
     const int r = lane & 31, hh = lane >> 5;
     const int kw = wave & 3;                  // old k-step this wave converts (in its blocks)
-    const float S = bits_to_float((unsigned)(127 + se) << 23);
+    const float S = exp2_bits(row_scale_exp(a, gt * 32 + r));   // this lane converts row r of the tile
     const unsigned to = (unsigned)((4 * hh + 8 * kw) * 4);
     const unsigned po = (unsigned)(tg * 32 + (lane & 15)) * 8u;
     const unsigned bo = (unsigned)tg * (KS * 4 * 1024u) + (unsigned)lane * 16u;
@@ -754,7 +765,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((target("no-packed-fp32-ops")
         unsigned tid2 = threadIdx.x;
         asm volatile("" : "+v"(tid2));
         const int lane2 = (int)(tid2 & 63u);
-        const float invS = bits_to_float((unsigned)(127 - se) << 23) * sh.unscale;
+        const int se_self = row_scale_exp(a, gt * 32 + (lane2 & 31));   // again: nothing lives across the assembly
         float16v accr, acci;
         const float4v *acc = reinterpret_cast<const float4v *>(lds) + wave * 512 + lane2;
 #pragma unroll
@@ -766,7 +777,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((target("no-packed-fp32-ops")
                 acci[qd * 4 + j] = vi[j];
             }
         }
-        store_tile16(a, gt, tg, lane2, invS, accr, acci);
+        store_tile16(a, gt, tg, lane2, se_self, accr, acci);
     }
     stamp(1);
 }
@@ -785,11 +796,8 @@ __global__ __launch_bounds__(256) __attribute__((target("no-packed-fp32-ops"))) 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const int gt = blockIdx.x / nhi, blk = blockIdx.x - gt * nhi;
-    const unsigned mb = slot_max(a.maxbits, sh.slot_cur, sh.slot_prev);
-    int se = 140 - (int)((mb >> 23) & 0xffu);
-    se = se > 100 ? 100 : (se < -100 ? -100 : se);
-    const float S = bits_to_float((unsigned)(127 + se) << 23);
     const int o = gt * 32 + r;
+    const float S = exp2_bits(row_scale_exp(a, o));
     const int oc = o < sh.nout ? o : sh.nout - 1;
     const float2 *xbase = gt == 0 ? a.head + sh.carry_len : (gt == sh.ngt - 1 ? a.tail - sh.tail0 : a.x);
     const int k = blk * 4 + wave;       // 8-sample k-step of the window
@@ -803,7 +811,7 @@ __global__ __launch_bounds__(256) __attribute__((target("no-packed-fp32-ops"))) 
 }
 
 __device__ __forceinline__ __attribute__((target("no-packed-fp32-ops"))) void ring16p_tile(
-    const MfmaLaunch &a, uint4 *lds, int gt, int first, int se, int tg, int wave, bool active) {
+    const MfmaLaunch &a, uint4 *lds, int gt, int first, int tg, int wave, bool active) {
     constexpr int KS = 4;
     const MfmaShape &sh = a.sh;
     const int Np = sh.NT32 * 32;
@@ -840,7 +848,7 @@ __device__ __forceinline__ __attribute__((target("no-packed-fp32-ops"))) void ri
         unsigned tid2 = threadIdx.x;
         asm volatile("" : "+v"(tid2));
         const int lane2 = (int)(tid2 & 63u);
-        const float invS = bits_to_float((unsigned)(127 - se) << 23) * sh.unscale;
+        const int se_self = row_scale_exp(a, gt * 32 + (lane2 & 31));   // again: nothing lives across the assembly
         float16v accr, acci;
         const float4v *acc = reinterpret_cast<const float4v *>(lds) + wave * 512 + lane2;
 #pragma unroll
@@ -852,7 +860,7 @@ __device__ __forceinline__ __attribute__((target("no-packed-fp32-ops"))) void ri
                 acci[qd * 4 + j] = vi[j];
             }
         }
-        store_tile16(a, gt, tg, lane2, invS, accr, acci);
+        store_tile16(a, gt, tg, lane2, se_self, accr, acci);
     }
 }
 
@@ -870,115 +878,102 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
     const int tg_raw = (q % sh.ntq) * W + wave;
     const bool active = tg_raw < sh.ntg;
     const int tg = active ? tg_raw : sh.ntg - 1;
-    const unsigned mb = slot_max(a.maxbits, sh.slot_cur, sh.slot_prev);
-    int se = 140 - (int)((mb >> 23) & 0xffu);
-    se = se > 100 ? 100 : (se < -100 ? -100 : se);
-    ring16p_tile(a, lds, gt0, 1, se, tg, wave, active);
+    ring16p_tile(a, lds, gt0, 1, tg, wave, active);
 }
 
-// One pass over the new buffer x[0..n):
-//   * max |component| as float bits -> atomicMax(slots[cur]); slots[next] = 0;
-//   * head_cur[carry_len + i] = x[i] for i < head_n (row tile 0 reads [carry | x) there);
-//   * head_next[i - (n - carry_len)] = x[i] for the last carry_len samples (next call's carry);
-//   * tail[i - tail0] = x[i] for i >= tail0 (the last row tile reads there; zeros follow).
-// All destinations may be null.  Workgroups from `main_blocks` on copy extra_src[0..extra_n)
-// to extra_dst (TONES: the unconsumed end of the previous raw window to the front of this
-// one; its maximum is in the previous call's slot already).
-__global__ __launch_bounds__(256) void absmax_kernel(const float2 *x, long long n, long long chunk,
-                                                     unsigned *slots, int cur, int next, float2 *head_cur,
-                                                     long long head_n, float2 *head_next, int carry_len,
-                                                     float2 *tail, long long tail0, unsigned main_blocks,
-                                                     const float2 *extra_src, float2 *extra_dst,
-                                                     long long extra_n) {
-    if (blockIdx.x >= main_blocks) {
-        const long long e0 = (long long)(blockIdx.x - main_blocks) * chunk;
-        const long long e1 = e0 + chunk < extra_n ? e0 + chunk : extra_n;
-        for (long long base = e0 + threadIdx.x; base < e1; base += 1024) {
-            float2 v[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = base + 256 * k < e1 ? extra_src[base + 256 * k] : make_float2(0.f, 0.f);
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (base + 256 * k < e1) extra_dst[base + 256 * k] = v[k];
-        }
-        return;
-    }
-    // one contiguous chunk of samples per workgroup (chunk is even)
-    const long long c0 = (long long)blockIdx.x * chunk;
-    const long long c1 = c0 + chunk < n ? c0 + chunk : n;
+// The staging pass (StageLaunch in ddc_kernels.h).  One wave per piece: a piece is a segment of the
+// maxima table, or 1/pps of one when segments are long; a wave scans the part of its piece that lies in B
+// (what the previous call left in front), then the part in A (the new buffer), sixteen bytes per lane and
+// load, four loads in flight, and folds its maximum into the segment's entry with one atomicMax (float bits
+// of non-negative numbers order like unsigned integers; entries are hit by pps waves, plus one more where a
+// segment straddles B and A).  NaN and Inf patterns count as zero: they must not set a scale (see
+// row_scale_exp).  The copies for the main kernels ride along in the pieces that touch their ranges.
+struct StageShape {
+    long long seg_len, plen;   // samples per segment and per piece (plen even)
+    int pps;                   // pieces per segment
+    long long ttot;            // nb + n
+};
+
+__device__ __forceinline__ unsigned finite_bits(float v) {
+    const unsigned b = __builtin_bit_cast(unsigned, v) & 0x7fffffffu;
+    return b < 0x7f800000u ? b : 0u;
+}
+
+template <bool COPY>
+__device__ __forceinline__ unsigned stage_scan(const StageLaunch &s, const float2 *src, long long i0, long long i1,
+                                               int lane, float2 *dst) {
+    // samples src[i0 .. i1); COPY: region A with the head/tail copies; dst != null: region B copied to dst
     unsigned m = 0;
-    const bool copies = (head_cur && c0 < head_n) || (head_next && c1 > n - carry_len) || (tail && c1 > tail0);
-    if (!copies) {
-        // fast path: 16-byte loads (two samples), four in flight per thread
-        const float4u *x4 = reinterpret_cast<const float4u *>(x + c0);
-        const long long pairs = (c1 - c0) >> 1;
-        long long i = threadIdx.x;
-        for (; i + 768 < pairs; i += 1024) {
-            const float4u v0 = x4[i], v1 = x4[i + 256], v2 = x4[i + 512], v3 = x4[i + 768];
-            const float4u q[4] = {v0, v1, v2, v3};
+    for (long long base = i0 + 2 * lane; base < i1; base += 512) {
+        float4u v[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const unsigned b0 = __float_as_uint(q[k].x) & 0x7fffffffu, b1 = __float_as_uint(q[k].y) & 0x7fffffffu;
-                const unsigned b2 = __float_as_uint(q[k].z) & 0x7fffffffu, b3 = __float_as_uint(q[k].w) & 0x7fffffffu;
-                const unsigned u = b0 > b1 ? b0 : b1, w = b2 > b3 ? b2 : b3;
-                const unsigned t = u > w ? u : w;
-                m = m > t ? m : t;
+        for (int k = 0; k < 4; ++k) {
+            const long long i = base + 128 * k;
+            if (i + 1 < i1) {
+                v[k] = *reinterpret_cast<const float4u *>(src + i);
+            } else if (i < i1) {
+                const float2 w = src[i];
+                v[k] = float4u{w.x, w.y, 0.f, 0.f};
+            } else {
+                v[k] = float4u{0.f, 0.f, 0.f, 0.f};
             }
         }
-        for (; i < pairs; i += 256) {
-            const float4u v = x4[i];
-            const unsigned b0 = __float_as_uint(v.x) & 0x7fffffffu, b1 = __float_as_uint(v.y) & 0x7fffffffu;
-            const unsigned b2 = __float_as_uint(v.z) & 0x7fffffffu, b3 = __float_as_uint(v.w) & 0x7fffffffu;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long long i = base + 128 * k;
+            const unsigned b0 = finite_bits(v[k].x), b1 = finite_bits(v[k].y), b2 = finite_bits(v[k].z),
+                           b3 = finite_bits(v[k].w);
             const unsigned u = b0 > b1 ? b0 : b1, w = b2 > b3 ? b2 : b3;
             const unsigned t = u > w ? u : w;
             m = m > t ? m : t;
-        }
-        if (((c1 - c0) & 1) && threadIdx.x == 0) {
-            const float2 v = x[c1 - 1];
-            const unsigned b0 = __float_as_uint(v.x) & 0x7fffffffu, b1 = __float_as_uint(v.y) & 0x7fffffffu;
-            const unsigned t = b0 > b1 ? b0 : b1;
-            m = m > t ? m : t;
-        }
-    } else {
-        // chunk with copies: eight samples per thread in flight (the stores may alias
-        // nothing here, but the compiler cannot know: load first, then store)
-        for (long long base = c0 + threadIdx.x; base < c1; base += 2048) {
-            float2 v[8];
+            if (COPY || dst) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const long long i = base + 256 * k;
-                v[k] = i < c1 ? x[i] : make_float2(0.f, 0.f);
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const long long i = base + 256 * k;
-                if (i < c1) {
-                    const unsigned b0 = __float_as_uint(v[k].x) & 0x7fffffffu, b1 = __float_as_uint(v[k].y) & 0x7fffffffu;
-                    const unsigned t = b0 > b1 ? b0 : b1;
-                    m = m > t ? m : t;
-                    if (head_cur && i < head_n) head_cur[carry_len + i] = v[k];
-                    if (head_next && i >= n - carry_len) head_next[i - (n - carry_len)] = v[k];
-                    if (tail && i >= tail0) tail[i - tail0] = v[k];
+                for (int e = 0; e < 2; ++e) {
+                    const long long ie = i + e;
+                    if (ie >= i1) break;
+                    const float2 w2 = e ? make_float2(v[k].z, v[k].w) : make_float2(v[k].x, v[k].y);
+                    if (COPY) {
+                        if (s.head_cur && ie < s.head_n) s.head_cur[s.carry_len + ie] = w2;
+                        if (s.head_next && ie >= s.n - s.carry_len) s.head_next[ie - (s.n - s.carry_len)] = w2;
+                        if (s.tail && ie >= s.tail0) s.tail[ie - s.tail0] = w2;
+                    } else {
+                        dst[ie] = w2;
+                    }
                 }
             }
         }
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const unsigned t = (unsigned)__shfl_xor((int)m, d);
-        m = m > t ? m : t;
+    return m;
+}
+
+__global__ __launch_bounds__(256) void absmax_kernel(const StageLaunch s, const StageShape g) {
+    // the table of the next call
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < s.nseg_alloc; i += (long long)gridDim.x * 256)
+        s.seg_clear[i] = 0u;
+    const int lane = threadIdx.x & 63;
+    const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);     // piece
+    const long long q = w / g.pps;
+    const int r = (int)(w - q * g.pps);
+    long long t0 = q * g.seg_len + (long long)r * g.plen, t1 = t0 + g.plen;
+    const long long seg_end = (q + 1) * g.seg_len;
+    if (t1 > seg_end) t1 = seg_end;
+    if (t1 > g.ttot) t1 = g.ttot;
+    if (t0 >= t1) return;        // wave-uniform
+    unsigned m = 0;
+    if (t0 < s.nb) {
+        const long long e = t1 < s.nb ? t1 : s.nb;
+        m = stage_scan<false>(s, s.b, t0, e, lane, s.b_dst);
     }
-    // one atomic per workgroup, kAbsmaxPartials addresses per slot (see slot_max); workgroup 0 clears
-    // the slot of the next call
-    __shared__ unsigned wmax[4];
-    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned u = wmax[0] > wmax[1] ? wmax[0] : wmax[1], w = wmax[2] > wmax[3] ? wmax[2] : wmax[3];
-        const unsigned t = u > w ? u : w;
-        if (t) atomicMax(&slots[(size_t)cur * kAbsmaxPartials + (blockIdx.x % kAbsmaxPartials)], t);
+    if (t1 > s.nb) {
+        const long long i0 = (t0 > s.nb ? t0 : s.nb) - s.nb, i1 = t1 - s.nb;
+        const bool copies = (s.head_cur && i0 < s.head_n) || (s.head_next && i1 > s.n - s.carry_len) ||
+                            (s.tail && i1 > s.tail0);
+        const unsigned ma = copies ? stage_scan<true>(s, s.x, i0, i1, lane, nullptr)
+                                   : stage_scan<false>(s, s.x, i0, i1, lane, nullptr);
+        m = m > ma ? m : ma;
     }
-    if (blockIdx.x == 0 && threadIdx.x < kAbsmaxPartials) slots[(size_t)next * kAbsmaxPartials + threadIdx.x] = 0u;
+    m = wave_max_u32(m);
+    if (lane == 0 && m) atomicMax(&s.seg[q], m);
 }
 
 // ---------------------------------------------------------------------------
@@ -1119,29 +1114,29 @@ void mfma_build_tables(const MfmaPlan &pl, const std::vector<unsigned> &fmod_in,
     for (int t = 0; t < pl.MF; ++t) taps[t] = std::ldexp(window[t], -eh);
 }
 
-hipError_t launch_absmax(const float2 *x, long long n, unsigned *slots, int cur, int next,
-                         float2 *head_cur, long long head_n, float2 *head_next, int carry_len,
-                         float2 *tail, long long tail0, hipStream_t st, const float2 *extra_src,
-                         float2 *extra_dst, long long extra_n) {
-    if (n < 1 || carry_len < 0 || carry_len > n || head_n < 0 || head_n > n || tail0 < 0 || tail0 > n ||
-        extra_n < 0 || (extra_n > 0 && (!extra_src || !extra_dst)))
+hipError_t launch_absmax(const StageLaunch &s, hipStream_t st) {
+    if (!s.x || s.n < 1 || s.nb < 0 || (s.nb > 0 && !s.b) || s.carry_len < 0 || s.carry_len > s.n || s.head_n < 0 ||
+        s.head_n > s.n || s.tail0 < 0 || s.tail0 > s.n || !s.seg || !s.seg_clear || s.seg_len < 1 || s.nseg_alloc < 1)
         return hipErrorInvalidValue;
-    // samples per workgroup (GSDR_ABSMAX_CHUNK, default 2048), at most 4 * kAbsmaxPartials workgroups, even chunks
+    StageShape g{};
+    g.seg_len = s.seg_len;
+    g.ttot = s.nb + s.n;
+    const long long nseg = (g.ttot + s.seg_len - 1) / s.seg_len;
+    if (nseg > s.nseg_alloc) return hipErrorInvalidValue;
+    // pieces of at most ~1024 samples (GSDR_ABSMAX_CHUNK): a wave per piece
     static const long long want = [] {
         const char *e = std::getenv("GSDR_ABSMAX_CHUNK");
-        const long long v = e ? std::atoll(e) : 2048;
-        return v >= 512 ? v : 2048;
+        const long long v = e ? std::atoll(e) : 1024;
+        return v >= 128 ? v : 1024;
     }();
-    long long blocks = (n + want - 1) / want;
-    if (blocks > 4 * kAbsmaxPartials) blocks = 4 * kAbsmaxPartials;
-    if (blocks < 1) blocks = 1;
-    long long chunk = (n + blocks - 1) / blocks;
-    chunk += chunk & 1;
-    blocks = (n + chunk - 1) / chunk;
-    const long long extra_blocks = (extra_n + chunk - 1) / chunk;
-    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks + extra_blocks)), dim3(256), 0, st, x, n, chunk, slots,
-                       cur, next, head_cur, head_n, head_next, carry_len, tail, tail0, (unsigned)blocks, extra_src,
-                       extra_dst, extra_n);
+    g.pps = (int)((s.seg_len + want - 1) / want);
+    if (g.pps < 1) g.pps = 1;
+    g.plen = (s.seg_len + g.pps - 1) / g.pps;
+    g.plen += g.plen & 1;
+    const long long pieces = nseg * g.pps;
+    const long long blocks = (pieces + 3) / 4;
+    if (blocks < 1 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, s, g);
     return hipGetLastError();
 }
 
@@ -1154,7 +1149,7 @@ hipError_t launch_ddc_mfma(MfmaKernel kind, int TT, int PK, int W, const MfmaLau
         (long long)(sh.nout - 1 + sh.woff) * sh.M + sh.MF > sh.nx ||
         (long long)sh.woff * sh.M + sh.carry_len < 0 || (sh.woff < 0 && -sh.woff > 32) ||
         !a.x || !a.head || !a.tail || !a.out || !a.bfrag || !a.ptab || !a.dtab || !a.taps ||
-        !a.fmod || !a.maxbits)
+        !a.fmod || !a.segmax || sh.seg_k < 1)
         return hipErrorInvalidValue;
     // the row tiles between the first and the last read a.x directly, 8 samples at a time
     // (TONES passes its own over-allocated window as x, head and tail alike); a row

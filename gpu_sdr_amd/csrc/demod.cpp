@@ -113,7 +113,10 @@ struct gsdr_demod {
     uint4 *d_bfrag = nullptr;
     float2 *d_ptab = nullptr, *d_dtab = nullptr;
     float *d_mtaps = nullptr;
-    unsigned *d_mfmod = nullptr, *d_maxbits = nullptr;
+    unsigned *d_mfmod = nullptr;
+    // kScaleSlots tables of segment maxima (absmax_kernel), one per call in turn; seg_k blocks of M samples per segment
+    unsigned *d_segmax = nullptr;
+    int seg_k = 1, nseg_alloc = 0;
     // [carry | first rows' samples | zeros] and [last rows' samples | zeros], see absmax_kernel.
     // kStageSets of each, used in turn: the staging pass of call j writes set j (and the carry
     // part of head j+1) while the main kernels of calls j-1 .. j-kPipeStreams+1 may still read theirs.
@@ -432,8 +435,16 @@ int setup_mfma(gsdr_demod *h, bool direct, const std::vector<long long> &tone) {
     HIPCHK(h, upload(&h->d_dtab, dtab));
     HIPCHK(h, upload(&h->d_mtaps, taps));
     HIPCHK(h, upload(&h->d_mfmod, fmod));
-    HIPCHK(h, dev_alloc(&h->d_maxbits, kScaleSlots * gsdr::kAbsmaxPartials));   // slots of partial maxima
-    HIPCHK(h, hipMemset(h->d_maxbits, 0, kScaleSlots * gsdr::kAbsmaxPartials * sizeof(unsigned)));
+    {
+        // maxima per segment of the call's logical stream [carry | buffer] (TONES: the raw window, allocated
+        // 2 * nfft * batching long): a segment is one block of M samples, several when blocks are short
+        h->seg_k = M >= 64 ? 1 : (64 + M - 1) / M;
+        const long long t_max = direct ? (long long)(F - 1) * M + h->L : 2LL * h->nfft * h->batching;
+        const long long seg_len = (long long)h->seg_k * M;
+        h->nseg_alloc = (int)((t_max + seg_len - 1) / seg_len) + 2;
+        HIPCHK(h, dev_alloc(&h->d_segmax, (size_t)kScaleSlots * h->nseg_alloc));
+        HIPCHK(h, hipMemset(h->d_segmax, 0, (size_t)kScaleSlots * h->nseg_alloc * sizeof(unsigned)));
+    }
     gsdr::MfmaShape &sh = h->mf;
     sh.N = h->ddc_channels;
     sh.NT32 = pl.ntg * pl.TT;
@@ -625,11 +636,10 @@ int autotune_chunks(gsdr_demod *h, int nblk) {
 int enqueue_mfma(gsdr_demod *h, const float2 *in, float2 *raw, long long raw_new0, long long nx,
                  int nout, unsigned idx_base, float2 *out, hipStream_t st, const float2 *spare_src,
                  long long spare_n) {
-    // slots: this buffer, the previous one, the one the staging pass clears for the next call.
-    // kScaleSlots of them, so that the pass of call j (writing slot j, clearing slot j+1) leaves
-    // alone what the main kernels of the calls still in flight read (slots j-1 .. j-kPipeStreams).
-    const int cur = (int)(h->call_no % kScaleSlots), prev = (int)((h->call_no + kScaleSlots - 1) % kScaleSlots),
-              next = (int)((h->call_no + 1) % kScaleSlots);
+    // tables of segment maxima: this call's, and the one the staging pass clears for the next call.
+    // kScaleSlots of them, so that the pass of call j (filling table j, clearing table j+1) leaves
+    // alone what the main kernels of the calls still in flight read (tables j-1 .. j-kPipeStreams+1).
+    const int cur = (int)(h->call_no % kScaleSlots), next = (int)((h->call_no + 1) % kScaleSlots);
     const int hs = (int)(h->call_no % kStageSets), hs_next = (int)((h->call_no + 1) % kStageSets);
     gsdr::MfmaLaunch a{};
     a.sh = h->mf;
@@ -637,8 +647,14 @@ int enqueue_mfma(gsdr_demod *h, const float2 *in, float2 *raw, long long raw_new
     a.sh.ngt = (nout + 31) / 32;
     a.sh.nx = nx;
     a.sh.idx_base = idx_base;
-    a.sh.slot_cur = cur;
-    a.sh.slot_prev = prev;
+    a.sh.seg_k = h->seg_k;
+    gsdr::StageLaunch sg{};
+    sg.x = in;
+    sg.n = h->L;
+    sg.seg = h->d_segmax + (size_t)cur * h->nseg_alloc;
+    sg.seg_clear = h->d_segmax + (size_t)next * h->nseg_alloc;
+    sg.nseg_alloc = h->nseg_alloc;
+    sg.seg_len = (long long)h->seg_k * a.sh.M;
     if (a.sh.rt == 0) {
         // Two row tiles per workgroup (the second keeps the phasor images: 64 KiB less to load, one
         // preamble less, half as many workgroups).  Measured at decim 100 (13-block windows) for
@@ -656,8 +672,17 @@ int enqueue_mfma(gsdr_demod *h, const float2 *in, float2 *raw, long long raw_new
         // TONES: one pass brings the carried samples to the front of this call's raw window,
         // appends the buffer and takes its maximum; every row reads the window itself
         // (allocated twice as long as it gets)
-        HIPCHK(h, gsdr::launch_absmax(in, h->L, h->d_maxbits, cur, next, raw + raw_new0, h->L, nullptr, 0,
-                                      nullptr, h->L, st, spare_src, raw, spare_n));
+        if (spare_n != raw_new0) {
+            h->err = "raw window bookkeeping out of step";
+            return -1;
+        }
+        sg.b = spare_src;
+        sg.nb = spare_n;
+        sg.b_dst = raw;
+        sg.head_cur = raw + raw_new0;
+        sg.head_n = h->L;
+        sg.tail0 = h->L;
+        HIPCHK(h, gsdr::launch_absmax(sg, st));
         if (h->pipe_overlap) HIPCHK(h, hipEventRecord(h->ev_abs[h->pipe_seq % 4], st));
         a.x = a.head = a.tail = raw;
         a.sh.tail0 = 0;
@@ -667,8 +692,15 @@ int enqueue_mfma(gsdr_demod *h, const float2 *in, float2 *raw, long long raw_new
         const int ks = h->mf_PK / 8;
         long long head_n = 32LL * a.sh.M + (long long)((a.sh.nk8 + ks - 1) / ks) * h->mf_PK + 8;
         if (head_n > h->L) head_n = h->L;
-        HIPCHK(h, gsdr::launch_absmax(in, h->L, h->d_maxbits, cur, next, h->d_head[hs], head_n,
-                                      h->d_head[hs_next], cl, h->d_tail[hs], t0, st));
+        sg.b = h->d_head[hs];       // the carry: the last cl samples of the previous buffer, left there by its pass
+        sg.nb = cl;
+        sg.head_cur = h->d_head[hs];
+        sg.head_n = head_n;
+        sg.head_next = h->d_head[hs_next];
+        sg.carry_len = cl;
+        sg.tail = h->d_tail[hs];
+        sg.tail0 = t0;
+        HIPCHK(h, gsdr::launch_absmax(sg, st));
         if (h->pipe_overlap) HIPCHK(h, hipEventRecord(h->ev_abs[h->pipe_seq % 4], st));
         a.x = in;
         a.head = h->d_head[hs];
@@ -680,7 +712,7 @@ int enqueue_mfma(gsdr_demod *h, const float2 *in, float2 *raw, long long raw_new
     a.ptab = h->d_ptab;
     a.dtab = h->d_dtab;
     a.fmod = h->d_mfmod;
-    a.maxbits = h->d_maxbits;
+    a.segmax = sg.seg;
     a.out = out;
     hipEvent_t stop = nullptr;
     if (record_begin(h, st, &stop)) return -1;
@@ -1600,7 +1632,7 @@ void gsdr_demod_close(gsdr_demod *h) {
                     h->d_wrem,    h->d_fmod,    h->d_tails,    h->d_carry[0], h->d_carry[1],
                     h->d_profile, h->d_ccarry[0], h->d_ccarry[1],
                     h->d_bfrag,   h->d_ptab,    h->d_dtab,     h->d_mtaps,    h->d_mfmod,
-                    h->d_maxbits};
+                    h->d_segmax};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (int i = 0; i < kStageSets; ++i) {

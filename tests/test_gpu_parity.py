@@ -496,6 +496,80 @@ def test_direct_isolated_spike(cuda_device, gsdr_lib, oracle_mod, monkeypatch, i
     assert far <= TOL, (impl, far)
 
 
+EXTREME_ENGINES = {
+    # name: (GSDR_DDC_MFMA, GSDR_DDC_PIPE, GSDR_MFMA_ASM, GSDR_MFMA_PREC)
+    "flat": ("0", "1", "4", "0"),        # packed-FP32 VALU kernel (north_star's arithmetic)
+    "generic": ("0", "0", "4", "0"),     # compiler-scheduled FP32 VALU kernel
+    "mfma16": ("1", "1", "4", "0"),      # the default matrix-core loop
+    "mfma16w8": ("1", "1", "5", "0"),
+    "mfma16p": ("1", "1", "4", "1"),
+    "mfma32": ("1", "1", "2", "0"),
+    "mfmacxx": ("1", "1", "0", "0"),
+}
+
+
+@pytest.mark.parametrize("impl", list(EXTREME_ENGINES))
+@pytest.mark.parametrize("kind", ["1e8", "1e10", "inf", "nan"])
+@pytest.mark.parametrize("shape", [(16, 10_000_000, 100, 4, 100_000), (32, 200_000_000, 1000, 4, 200_000),
+                                   (12, 9_000_000, 90, 4, 90_000)], ids=["M100", "M1000", "M90pad"])
+def test_direct_extreme_and_nonfinite_samples(cuda_device, gsdr_lib, oracle_mod, monkeypatch, impl, kind, shape):
+    """One sample at 1e8 x / 1e10 x the signal's rms, one Inf, one NaN, in the second buffer of four.
+    In the reference a bad sample reaches only the outputs whose window holds it: the mix is elementwise
+    (ref: cpp/kernels.cu:82-83) and the FIR sums one window (ref: cpp/fir.cu:48-61).  The same must
+    hold here on every engine -- the matrix-core engines scale every output row from the finite maximum of
+    its own window (row_scale_exp, csrc/ddc_mfma.hip), so a spike costs the other rows nothing:
+      * rows whose window does not hold the sample: <= 1e-5 per tone in EVERY buffer;
+      * rows that hold a finite spike: <= 1e-5 per tone as well (the spike term dominates them);
+      * rows that hold the Inf / NaN: non-finite exactly where the oracle's outputs are.
+    The sample sits 3 samples behind a block boundary: for the "M90pad" shape that is inside the zero-padded
+    tail of the previous rows' windows (M*F = 360 is not a whole number of 32-sample blocks), which must not
+    let it through either (0 * Inf)."""
+    N, rate, M, F, L = shape
+    mf, pipe, asm, prec = EXTREME_ENGINES[impl]
+    monkeypatch.setenv("GSDR_DDC_MFMA", mf)
+    monkeypatch.setenv("GSDR_DDC_PIPE", pipe)
+    monkeypatch.setenv("GSDR_MFMA_ASM", asm)
+    monkeypatch.setenv("GSDR_MFMA_PREC", prec)
+    from gpu_sdr_amd.source import host_tones, tone_comb
+    freq, ampl, phase = tone_comb(N, rate, seed=77)
+    dem = make_direct(freq, rate, M, F, L)
+    assert dem.kernel_name.startswith("ddc_mfma") == (mf == "1"), dem.kernel_name
+    ref = oracle_mod.Direct(freq, rate, M, F, L)
+    at = (L // M // 2) * M + 3
+    rows = np.arange(L // M)
+    hit = (rows >= at // M) & (rows <= at // M + F - 1)      # output row G covers samples (G-F+1)*M .. (G+1)*M
+    far = near = 0.0
+    for c in range(4):
+        x = host_tones(L, c * L, rate, freq, ampl, phase, sigma=1e-3, seed=700 + c)
+        if c == 1:
+            rms = float(np.sqrt(np.mean(np.abs(x) ** 2)))
+            x[at] = {"1e8": np.complex64(1e8 * rms * (0.6 + 0.8j)), "1e10": np.complex64(1e10 * rms * (0.6 - 0.8j)),
+                     "inf": np.complex64(complex(np.inf, 0.5)), "nan": np.complex64(complex(0.25, np.nan))}[kind]
+        y = run_device(dem, x, cuda_device).reshape(-1, N)
+        with np.errstate(invalid="ignore", over="ignore"):
+            yr = ref.process(x)
+        assert y.shape == yr.shape
+        fin_y = np.isfinite(y.real) & np.isfinite(y.imag)
+        fin_r = np.isfinite(yr.real) & np.isfinite(yr.imag)
+        if c == 1:
+            if kind in ("inf", "nan"):
+                assert not fin_r[hit].any(), "the oracle's rows that hold the sample are non-finite"
+                np.testing.assert_array_equal(fin_y, fin_r, err_msg=f"{impl} {kind}: non-finite outputs elsewhere than the oracle's")
+            else:
+                assert fin_y.all()
+                near = max(near, float(rel_err_per_tone(y[hit], yr[hit], "rows whose window holds the spike").max()))
+            keep = ~hit
+            keep[:F] = False
+            e = rel_err_per_tone(y[keep], yr[keep], "rows of the bad sample's buffer that do not hold it")
+        else:
+            assert fin_y.all(), (impl, kind, c)
+            e = rel_err_per_tone(y[F:] if c == 0 else y, yr[F:] if c == 0 else yr, "the other buffers")
+        far = max(far, float(e.max()))
+    dem.close()
+    assert far <= TOL, (impl, kind, far)
+    assert near <= TOL, (impl, kind, near)
+
+
 def test_direct_streaming_equals_one_long_buffer(cuda_device, gsdr_lib, engine):
     """Concatenated per-buffer outputs == one call on the concatenated input."""
     rate, M, F, N = 1_000_000, 100, 4, 9

@@ -157,8 +157,8 @@ def produce_ops(xa=None, xb=None, hv=None):
         ops.append(f"v_mul_f32 {vr(HS + j)}, {vr(hv + j)}, {vr(V_SC)}")
     xs = [xa, xa + 2, xb, xb + 2]
     for j in range(4):
-        ops.append(f"v_mul_f32 {vr(xs[j])}, {vr(xs[j])}, {vr(HS + j)}")
-        ops.append(f"v_mul_f32 {vr(xs[j] + 1)}, {vr(xs[j] + 1)}, {vr(HS + j)}")
+        ops.append(f"v_mul_legacy_f32 {vr(xs[j])}, {vr(xs[j])}, {vr(HS + j)}")   # 0 * anything = 0: zero-padded taps meet samples outside the window
+        ops.append(f"v_mul_legacy_f32 {vr(xs[j] + 1)}, {vr(xs[j] + 1)}, {vr(HS + j)}")
     for j in range(4):
         ops.append(f"v_cvt_pk_f16_f32 {vr(HI4 + j)}, {vr(xs[j])}, {vr(xs[j] + 1)}")
     for j in range(4):

@@ -154,8 +154,8 @@ def produce_ops(xa=None, xb=None, hv=None):
     xs = [xa, xa + 2, xb, xb + 2]
     if os.environ.get("GEN_CONV", "mul") == "mul":     # default; GEN_CONV=mix: 24 instructions through v_fma_mixlo/hi_f16, measured 1.2 % SLOWER on C3 (same box, scratch/ab.sh)
         for j in range(4):
-            ops.append(f"v_mul_f32 {vr(xs[j])}, {vr(xs[j])}, {vr(HS + j)}")
-            ops.append(f"v_mul_f32 {vr(xs[j] + 1)}, {vr(xs[j] + 1)}, {vr(HS + j)}")
+            ops.append(f"v_mul_legacy_f32 {vr(xs[j])}, {vr(xs[j])}, {vr(HS + j)}")   # 0 * anything = 0: zero-padded taps meet samples outside the window
+            ops.append(f"v_mul_legacy_f32 {vr(xs[j] + 1)}, {vr(xs[j] + 1)}, {vr(HS + j)}")
         for j in range(4):
             ops.append(f"v_cvt_pk_f16_f32 {vr(HI4 + j)}, {vr(xs[j])}, {vr(xs[j] + 1)}")
         for j in range(4):

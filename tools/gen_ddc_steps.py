@@ -31,9 +31,13 @@ def clobbers(x0, t0):
     return ", ".join(f'"s{r}"' for r in list(range(x0, x0 + 8)) + list(range(t0, t0 + 16)))
 
 
-def step(F, FP, cur_is_a, n, lo0, nxt_n, nxt_from_next, nxt_off, first=False):
+def step(F, FP, cur_is_a, n, lo0, nxt_n, nxt_from_next, nxt_off, first=False, masked=False):
     """asm text + operand lists of one step.  first: S is write-only (the very
-    first MAC of the sub-block is a multiply, so S needs no zeroing)."""
+    first MAC of the sub-block is a multiply, so S needs no zeroing).  masked: the last
+    sub-block of a block whose length is not a multiple of PK -- samples lo >= R belong to the
+    NEXT block and meet zero taps here; they are replaced by zeros on the scalar side (three SALU
+    instructions per sample), because 0 * Inf is NaN and a sample of the next block must not
+    reach this block's outputs whatever it is (ref: cpp/fir.cu:48-61 sums one window)."""
     cx, ct = (XA, TA) if cur_is_a else (XB, TB)
     nx, nt = (XB, TB) if cur_is_a else (XA, TA)
     lines = ["@W"]
@@ -42,6 +46,11 @@ def step(F, FP, cur_is_a, n, lo0, nxt_n, nxt_from_next, nxt_off, first=False):
     to = 0 if nxt_from_next else nxt_off * FP * 4
     lines.append("@L" + f"{LOADOP[2 * nxt_n]} {sreg(nx, 2 * nxt_n)}, {xp}, {xo}")
     lines.append("@L" + f"{LOADOP[nxt_n * FP]} {sreg(nt, nxt_n * FP)}, {tp}, {to}")
+    if masked:
+        for s in range(n):
+            lines.append(f"s_cmp_gt_u32 %[R], {lo0 + s}")
+            lines.append(f"s_cselect_b32 s{cx + 2 * s}, s{cx + 2 * s}, 0")
+            lines.append(f"s_cselect_b32 s{cx + 2 * s + 1}, s{cx + 2 * s + 1}, 0")
     for s in range(n):
         x = sreg(cx + 2 * s, 2)
         b = f"%[b{s}]"
@@ -62,7 +71,8 @@ def step(F, FP, cur_is_a, n, lo0, nxt_n, nxt_from_next, nxt_off, first=False):
     sc = '"=&v"' if first else '"+v"'
     outs = ", ".join([f'[s{j}] {sc}(S[{j}])' for j in range(F)] + ['[t] "=&v"(t)', '[u] "=&v"(u)'])
     ins = ", ".join([f'[b{s}] "v"(B[{lo0 + s}])' for s in range(n)] +
-                    (['[xn] "s"(xnext)', '[tn] "s"(tnext)'] if nxt_from_next else ['[xp] "s"(xg)', '[tp] "s"(tg)']))
+                    (['[xn] "s"(xnext)', '[tn] "s"(tnext)'] if nxt_from_next else ['[xp] "s"(xg)', '[tp] "s"(tg)']) +
+                    (['[R] "s"(R)'] if masked else []))
     def emit(ln):
         if ln == "@W":
             return "        GSDR_ASM_WAIT"
@@ -70,7 +80,10 @@ def step(F, FP, cur_is_a, n, lo0, nxt_n, nxt_from_next, nxt_off, first=False):
             return f'        GSDR_ASM_LOAD("{ln[2:]}\\n\\t")'
         return f'        "{ln}\\n\\t"'
     text = "\n".join(emit(ln) for ln in lines)
-    return f"    asm volatile(\n{text}\n        : {outs}\n        : {ins}\n        : {clobbers(nx, nt)});\n"
+    clob = clobbers(nx, nt)
+    if masked:
+        clob += ", " + ", ".join(f'"s{r}"' for r in range(cx, cx + 2 * n)) + ', "scc"'
+    return f"    asm volatile(\n{text}\n        : {outs}\n        : {ins}\n        : {clob});\n"
 
 
 def subblock(F, PK):
@@ -88,6 +101,19 @@ def subblock(F, PK):
         last = (k == len(sizes) - 1)
         nxt_n = sizes[0] if last else sizes[k + 1]
         out.append(step(F, FP, k % 2 == 0, n, lo, nxt_n, last, lo + n, first=(k == 0)))
+        lo += n
+    out.append("    }")
+    # the last sub-block of a block with M % PK != 0: only its first R samples are the block's
+    out += ["    // samples lo >= R are zeroed on the scalar side (see tools/gen_ddc_steps.py, step(masked=True))",
+            f"    static __device__ __forceinline__ void run_masked(f2v (&S)[{F}], const f2v (&B)[{PK}], const float2 *xg,",
+            "                                                      const float *tg, const float2 *xnext,",
+            "                                                      const float *tnext, int R) {",
+            "    f2v t, u;"]
+    lo = 0
+    for k, n in enumerate(sizes):
+        last = (k == len(sizes) - 1)
+        nxt_n = sizes[0] if last else sizes[k + 1]
+        out.append(step(F, FP, k % 2 == 0, n, lo, nxt_n, last, lo + n, first=(k == 0), masked=True))
         lo += n
     out.append("    }\n};\n")
     return "\n".join(out)
