@@ -140,6 +140,17 @@ def sum_over_ranks(dist, v: float, device=None) -> float:
     return float(t.item())
 
 
+def gather_over_ranks(dist, v: float, device=None):
+    """[v of rank 0, v of rank 1, ...] on every rank."""
+    if dist is None:
+        return [v]
+    import torch
+    t = torch.tensor([v], dtype=torch.float64, device=_ctl(device) or "cpu")
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
 def pick_backend(world: int, n_devices: int) -> str:
     """RCCL needs one device per rank ("Duplicate GPU detected" otherwise: that, and nothing
     else, is what stopped round 1's two-rank attempt on a one-GPU box); ranks that share a
@@ -347,7 +358,7 @@ def host_api_rates(wl, device, seed, seconds=0.4):
     return res
 
 
-def max_realtime_tones(engine, device, seed, budget_s=75.0):
+def max_realtime_tones(engine, device, seed, budget_s=75.0, api="pipelined"):
     """Largest N (multiple of 1024) sustaining >= 200 Msps over 200 consecutive
     1 M-sample buffers with decim=1000, f=4."""
     wl = dict(WORKLOADS["c3"])
@@ -356,7 +367,7 @@ def max_realtime_tones(engine, device, seed, budget_s=75.0):
     lo, hi = 2048, None
     n = 2048
     while time.perf_counter() - t_start < budget_s:
-        r = time_workload(engine, wl, device, seed, steps=200, warmup=5, n_tones=n, api="pipelined",
+        r = time_workload(engine, wl, device, seed, steps=200, warmup=5, n_tones=n, api=api,
                           fixed_repeats=1, profile_every=0)
         msps = 200 * L / r["elapsed"] / 1e6
         probes.append((n, round(msps, 1)))
@@ -581,12 +592,46 @@ def measure(engine, key, device, seed, steps, warmup, dist, api, min_seconds, wi
                     launches_in_flight=round(kt / (r["local_elapsed"] / r["total_steps"]), 2),
                     note="average launch duration inside the timed region of `value`, where up to "
                          f"{PIPE_DEPTH} launches share the chip")
+    if roof and ri is not r and not short_step and roof.get("bound") == "mfma":
+        # the entry `value` is timed through: what ran there, and the same algorithmic work over ITS time per buffer
+        _, af = algorithmic(wl, r["n_tones"])
+        step_s = r["local_elapsed"] / r["total_steps"]
+        conv = r["kernel"] == "ddc_mfma_ring16p_kernel"
+        roof["timed_entry"] = dict(
+            api=r["api"], kernels=["absmax_kernel"] + (["ddc_convert_kernel"] if conv else []) + [r["kernel"]],
+            gpu_us_per_buffer=round(step_s * 1e6, 2),
+            achieved=round(af * L / step_s / 1e12, 2), unit=roof["unit"], peak=roof["peak"],
+            frac=round(af * L / step_s / 1e12 / roof["peak"], 4),
+            note="algorithmic flops per buffer / time per buffer of the timed region (launches of consecutive buffers "
+                 "overlap there, so this is chip throughput, not one launch's duration) / the same peak")
     if roof and ri is not r and not short_step and ri["kernel"] != r["kernel"]:
         roof["note"] = (f"kernel / kernel_us are those of the in-order pass ({ri['kernel']}: the library picks the kernel per "
                         f"launch, DESIGN.md 4.1a/4.1b); the overlapped entry that `value` is timed through ran {r['kernel']} "
                         f"(+ ddc_convert_kernel when that is the pre-converted path); same tables, bit-identical results")
     res["roofline"], res["roofline_hbm"] = roof, roof_hbm
     return res
+
+
+def fp32_valu_extras(engine, device, seed):
+    """C3 through the engine that follows north_star's arithmetic to the letter -- fp32 multiplies on the VALU, no
+    matrix cores (GSDR_DDC_MFMA=0: ddc_flat_kernel, packed FP32; the reference multiplies in fp32 too: cuBLAS Cgemm,
+    cpp/fir.cu:48-54) -- as a figure at the reference's own arithmetic beside the headline."""
+    saved = os.environ.get("GSDR_DDC_MFMA")
+    os.environ["GSDR_DDC_MFMA"] = "0"       # read when a demodulator is created
+    try:
+        e = measure(engine, "c3", device, seed, steps=100, warmup=10, dist=None, api="inorder", min_seconds=0.5)
+        best, probes = max_realtime_tones(engine, device, seed, budget_s=40.0, api="inorder")
+    finally:
+        if saved is None:
+            del os.environ["GSDR_DDC_MFMA"]
+        else:
+            os.environ["GSDR_DDC_MFMA"] = saved
+    ro = e["roofline"] or {}
+    return dict(workload=WORKLOADS["c3"]["name"], engine=e["r"]["engine"], dtype="f32 (packed FP32 VALU multiplies and adds)",
+                msamples_per_s=round(e["value"], 2), api=e["r"]["api"], us_per_buffer=round(e["ms_per_step"] * 1e3, 2),
+                kernel=ro.get("kernel"), kernel_us=ro.get("kernel_us"), frac=ro.get("frac"), peak=ro.get("peak"),
+                achieved=ro.get("achieved"), unit=ro.get("unit"), roofline=ro,
+                max_realtime_tones_200Msps=dict(value=best, decim=1000, pf_average=4, buffers=200, probes=probes))
 
 
 # --------------------------------------------------------------------------
@@ -669,10 +714,12 @@ def main(argv=None, engine=None):
         "value": round(m["value"], 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "repeats": r["repeats"], "timed_region_s": round(r["elapsed"], 4),
         "ms_per_step": round(m["ms_per_step"], 5), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (f16 hi/lo-split MFMA, f32 accumulate)" if r["kernel"].startswith("ddc_mfma") else "f32",
         "dtype_note": ("complex64 in and out, fp32 accumulate; the DDC multiplies on the f16 MFMA as three products "
-                       "of hi/lo-split fp32 operands (error per tone vs the fp64 oracle: profiles/r02_parity_margins.json, "
-                       "bar 1e-5); chirp: fp32 VALU with an exact integer phase"),
+                       "of hi/lo-split fp32 operands under one power-of-two scale per output row (error per tone vs the "
+                       "fp64 oracle: profiles/r03_parity_margins.json, bar 1e-5; the same workload with fp32 multiplies on "
+                       "the VALU is extras.fp32_valu); chirp: fp32 VALU with an exact integer phase"),
         "data": "synthetic",
         "config": {"workload": wl["name"], "key": args.workload, "buffer_len": L,
                    "rate": wl.get("rate", RATE), "tones_per_stream": r["n_tones"],
@@ -690,6 +737,11 @@ def main(argv=None, engine=None):
     }
     if "inorder" in m:
         line["inorder"] = m["inorder"]
+    if world > 1:
+        # every rank's own clock around its own timed region: a straggler shows here, not only in the maximum
+        local = gather_over_ranks(dist, r["local_elapsed"], ctl_device)
+        line["per_rank"] = [dict(rank=i, msamples_per_s=round(r["total_steps"] * L / t / 1e6, 2),
+                                 ms_per_step=round(t / r["total_steps"] * 1e3, 5)) for i, t in enumerate(local)]
     if timing_env or "timing_build 0" not in build_info and not stub:
         line["INVALID"] = f"timing-only ablation build or switches ({timing_env or build_info}): not a benchmark"
 
@@ -714,6 +766,8 @@ def main(argv=None, engine=None):
             best, probes = max_realtime_tones(engine, device, seed)
             extras["max_realtime_tones_200Msps"] = dict(value=best, decim=1000, pf_average=4,
                                                         buffers=200, probes=probes)
+            if wl["kind"] == "direct":
+                extras["fp32_valu"] = fp32_valu_extras(engine, device, seed)
             line["extras"] = extras
         line.update(cpu)
     if rank == 0:

@@ -112,8 +112,13 @@ SIGNATURES = [
     ("gsdr_txgen_get", C.c_int, [C.c_void_p, C.c_void_p]),
     ("gsdr_txgen_get_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("gsdr_txgen_buffer_len", C.c_longlong, [C.c_void_p]),
+    ("gsdr_txgen_get_ptr", C.c_void_p, [C.c_void_p]),
+    ("gsdr_txgen_prepare_host", C.c_int, [C.c_void_p]),
+    ("gsdr_txgen_mode", C.c_int, [C.c_void_p]),
     ("gsdr_chirp_derive", None, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                  C.POINTER(ChirpParamC)]),
+    ("gsdr_chirp_derive_tx", None, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                    C.POINTER(ChirpParamC)]),
     ("gsdr_command_parse", _vp, [C.c_char_p, C.c_int]),
     ("gsdr_command_free", None, [_vp]),
     ("gsdr_command_error", C.c_char_p, []),
@@ -154,6 +159,8 @@ def lib() -> C.CDLL:
         try:
             fn = getattr(L, name)
         except AttributeError as e:
+            if os.environ.get("GSDR_LIB") and os.environ.get("GSDR_LIB_OLD_ABI"):
+                continue      # scratch/ A/B runs against a library of an earlier round (bench.py marks such lines INVALID)
             raise GsdrLibraryError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = restype
         fn.argtypes = argtypes

@@ -339,7 +339,17 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
     return z ^ (z >> 31);
 }
 
-__global__ __launch_bounds__(256) void source_tones_kernel(
+typedef float gsdr_f2 __attribute__((ext_vector_type(2)));
+// one 8-byte store (make_float2 is not always_inline: inside a no-packed-fp32-ops kernel it is a real call)
+__device__ __forceinline__ void store_c64(float2 *p, float re, float im) {
+    *reinterpret_cast<gsdr_f2 *>(p) = gsdr_f2{re, im};
+}
+
+// (Built without packed FP32 and without library calls like every kernel that may meet the matrix-core loop of
+// another handle on the GPU -- a TX generator beside the RX demodulators, ref:
+// cpp/USRP_server_link_threads.cpp:121,136; DESIGN.md section 4.1, rule 3.  Sines and cosines come from
+// sincos_index on a 32-bit fraction of a turn, the logarithm of the Box-Muller radius from v_log_f32.)
+__global__ __launch_bounds__(256) GSDR_NO_PK void source_tones_kernel(
     float2 *__restrict__ out, long long n, long long start, unsigned rate,
     const unsigned *__restrict__ fmod, const float *__restrict__ ampl,
     const float *__restrict__ phase, int n_tones, float sigma, unsigned long long seed) {
@@ -349,32 +359,32 @@ __global__ __launch_bounds__(256) void source_tones_kernel(
         const unsigned long long s = (unsigned long long)(start + j) % rate;
         float re = 0.f, im = 0.f;
         for (int k = 0; k < n_tones; ++k) {
-            // exact integer phase (f*s mod rate), then one float sincos
+            // exact integer phase (f*s mod rate) plus the tone's initial phase, as a fraction of a turn in
+            // double, then one sincos on its leading 32 bits
             const unsigned long long ph = ((unsigned long long)fmod[k] * s) % rate;
-            const float turns2 = (float)(2.0 * ((double)ph * inv_rate));
+            double turns = (double)ph * inv_rate + (double)phase[k] * 0.15915494309189533577;
+            turns -= __builtin_floor(turns);
+            const unsigned idx = (unsigned)(unsigned long long)(turns * 4294967296.0);
             float sn, cs;
-            sincospif(turns2, &sn, &cs);
-            float s0, c0;
-            sincosf(phase[k], &s0, &c0);
+            sincos_index((int)idx, sn, cs);
             const float a = ampl[k];
-            re += a * (cs * c0 - sn * s0);
-            im += a * (sn * c0 + cs * s0);
+            re += a * cs;
+            im += a * sn;
         }
         if (sigma > 0.f) {
             const unsigned long long h = mix64(seed ^ mix64((unsigned long long)(start + j)));
             const float u1 = ((float)(unsigned)(h >> 40) + 1.0f) * (1.0f / 16777217.0f);
-            const float u2 = (float)(unsigned)((h >> 8) & 0xffffffu) * (1.0f / 16777216.0f);
-            const float rad = sigma * sqrtf(-2.0f * logf(u1));
+            const float rad = sigma * __builtin_sqrtf(-1.3862943611198906f * __builtin_log2f(u1));   // sqrt(-2 ln u1)
             float sn, cs;
-            sincospif(2.0f * u2, &sn, &cs);
+            sincos_index((int)((unsigned)((h >> 8) & 0xffffffu) << 8), sn, cs);      // 24 bits of a turn
             re += rad * cs;
             im += rad * sn;
         }
-        out[j] = make_float2(re, im);
+        store_c64(out + j, re, im);
     }
 }
 
-__global__ __launch_bounds__(256) void source_chirp_kernel(float2 *__restrict__ out, long long n,
+__global__ __launch_bounds__(256) GSDR_NO_PK void source_chirp_kernel(float2 *__restrict__ out, long long n,
                                                            unsigned long long index0,
                                                            ChirpShape cs, float scale) {
     const bool small = cs.period < 0xffffffffull && cs.num_steps < 0xfffffffeull;
@@ -383,7 +393,7 @@ __global__ __launch_bounds__(256) void source_chirp_kernel(float2 *__restrict__ 
         const unsigned long long e = (index0 + (unsigned long long)o) % cs.period;
         float s, c;
         sincos_index(chirp_index(e, cs, small), s, c);
-        out[o] = make_float2(s * scale, -c * scale);  // ref: kernels.cu:367-368
+        store_c64(out + o, s * scale, -c * scale);  // ref: kernels.cu:367-368
     }
 }
 

@@ -75,6 +75,7 @@ struct MfmaShape {
     int ngt;                   // row tiles = ceil(nout / 32)
     int M;                     // samples per block
     int MF;                    // window length in samples (M * F)
+    int F;                     // tap phases (blocks of M samples a window spans)
     int nk8;                   // MFMA k-steps of 8 samples = ceil(MF / 8)
     int nout;                  // output rows of this launch
     int woff;                  // row o's window starts at sample (o + woff) * M

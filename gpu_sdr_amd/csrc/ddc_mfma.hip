@@ -178,23 +178,34 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
 // the maxima) turns into NaN exactly in the rows whose window holds it (x * h' * S overflows or stays NaN
 // in the conversion; zero-padded taps multiply with v_mul_legacy_f32, where 0 * anything = 0).
 // All kernels derive the same exponent from the same table: a stream may change kernels from call to call.
-__device__ __forceinline__ int row_scale_exp(const MfmaLaunch &a, int o) {
-    const MfmaShape &sh = a.sh;
+__device__ __forceinline__ void row_segments(const MfmaShape &sh, int o, int &q0, int &q1) {
     const int oc = o < sh.nout ? o : sh.nout - 1;
-    const int F = sh.MF / sh.M;
-    int q0 = oc, q1 = oc + F - 1;
+    q0 = oc;
+    q1 = oc + sh.F - 1;
     if (sh.seg_k > 1) {
         q0 /= sh.seg_k;
         q1 /= sh.seg_k;
     }
+}
+// The maxima of the (at most eight) segments of row o's window, all loads in flight at once.
+__device__ __forceinline__ unsigned row_max_bits(const MfmaLaunch &a, int o) {
+    int q0, q1;
+    row_segments(a.sh, o, q0, q1);
+    const int span = q1 - q0;
+    unsigned v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = a.segmax[q0 + (i < span ? i : span)];
     unsigned m = 0;
-    for (int q = q0; q <= q1; ++q) {
-        const unsigned v = a.segmax[q];
-        m = m > v ? m : v;
-    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m = m > v[i] ? m : v[i];
+    return m;
+}
+__device__ __forceinline__ int scale_exp_of(unsigned m) {
     int se = 140 - (int)((m >> 23) & 0xffu);
     return se > 100 ? 100 : (se < -100 ? -100 : se);
 }
+__device__ __forceinline__ int row_scale_exp(const MfmaLaunch &a, int o) { return scale_exp_of(row_max_bits(a, o)); }
+constexpr int kScaleFromTable = 0x7fffffff;
 __device__ __forceinline__ float exp2_bits(int e) { return __builtin_bit_cast(float, (unsigned)(127 + e) << 23); }
 
 // w_n^(idx_base + 32*gt*M): the phasor of tone n (fm = f_n mod rate) at the first row of
@@ -535,12 +546,15 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
 //                                                   tone 16*th + (l & 15) of the wave's 32.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ __attribute__((target("no-packed-fp32-ops"))) void store_tile16(
-    const MfmaLaunch &a, int gt, int tg, int lane, int se_self, const float16v &accr, const float16v &acci) {
+    const MfmaLaunch &a, int gt, int tg, int lane, int se_known, const float16v &accr, const float16v &acci) {
     const MfmaShape &sh = a.sh;
     const int Np = sh.NT32 * 32;
     const int l15 = lane & 15, l4 = lane >> 4;
-    // all table loads first (see store_tile); every lane computes the tile phasor of tone lane & 31
+    // all table loads first (see store_tile); every lane computes the tile phasor of tone lane & 31.
+    // se_known: the scale exponent of row lane & 31 of the tile as the loop left it in the LDS, or kScaleFromTable:
+    // the segment maxima are loaded again here (the kernel that copies pre-converted operands has no scale of its own)
     const unsigned fm = a.fmod[tg * 32 + (lane & 31)];
+    const unsigned mbits = se_known == kScaleFromTable ? row_max_bits(a, gt * 32 + (lane & 31)) : 0u;
     float2 d[16];
 #pragma unroll
     for (int th = 0; th < 2; ++th)
@@ -550,7 +564,18 @@ __device__ __forceinline__ __attribute__((target("no-packed-fp32-ops"))) void st
             for (int j = 0; j < 4; ++j)
                 d[4 * (2 * rh + th) + j] = a.dtab[(size_t)(16 * rh + 4 * l4 + j) * Np + tg * 32 + 16 * th + l15];
     asm volatile("" ::: "memory");
+    // the tile phasor first (fp64 arithmetic on a value loaded long ago): the segment maxima are still on their way
     const float2 base_self = tile_phasor(a, gt, fm);
+    asm volatile("" ::: "memory");
+    const int se_self = se_known == kScaleFromTable ? scale_exp_of(mbits) : se_known;
+    // 1 / S of the lane's eight rows (row 16*rh + 4*l4 + j lives in lane of the same number): all eight lane
+    // exchanges are issued before the first is used
+    float inv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = 16 * (i >> 2) + 4 * l4 + (i & 3);
+        inv[i] = exp2_bits(-__builtin_amdgcn_ds_bpermute(row << 2, se_self)) * sh.unscale;
+    }
 #pragma unroll
     for (int th = 0; th < 2; ++th) {
         // lane 16*th + l15 holds the tile phasor of tone 16*th + l15
@@ -564,9 +589,7 @@ __device__ __forceinline__ __attribute__((target("no-packed-fp32-ops"))) void st
             for (int j = 0; j < 4; ++j) {
                 const int i = 4 * (2 * rh + th) + j;
                 const int row = 16 * rh + 4 * l4 + j;
-                // 1 / S of this row (se_self: the exponent of row lane & 31, see row_scale_exp)
-                const float inv = exp2_bits(-__builtin_amdgcn_ds_bpermute(row << 2, se_self)) * sh.unscale;
-                const float dx = d[i].x * inv, dy = d[i].y * inv;
+                const float dx = d[i].x * inv[4 * rh + j], dy = d[i].y * inv[4 * rh + j];
                 const float rr = bx * dx - by * dy, ri = bx * dy + by * dx;
                 float2 y;
                 y.x = accr[i] * rr - acci[i] * ri;
@@ -578,7 +601,7 @@ __device__ __forceinline__ __attribute__((target("no-packed-fp32-ops"))) void st
 }
 
 __device__ __forceinline__ __attribute__((target("no-packed-fp32-ops"))) void ring16_tile(
-    const MfmaLaunch &a, uint4 *lds, int gt, int first, int tg, int wave, bool active) {
+    const MfmaLaunch &a, uint4 *lds, unsigned *lds_scale, int gt, int first, int tg, int wave, bool active) {
     constexpr int KS = 4;
     const MfmaShape &sh = a.sh;
     const int Np = sh.NT32 * 32;
@@ -587,7 +610,12 @@ __device__ __forceinline__ __attribute__((target("no-packed-fp32-ops"))) void ri
     asm volatile("" : "+v"(tid));
     const int lane = (int)(tid & 63u);
     const int r = lane & 31, hh = lane >> 5;
-    const float S = exp2_bits(row_scale_exp(a, gt * 32 + r));   // this lane converts row r of the tile
+    // this lane converts row r of the tile: the segments of the maxima table its window covers (the loop's
+    // prologue loads them and forms the scale, see scale_loads() in the generator)
+    int q0, q1;
+    row_segments(sh, gt * 32 + r, q0, q1);
+    const unsigned sgo = (unsigned)q0 * 4u, sgn = (unsigned)(q1 - q0);
+    const unsigned long long sgb = (unsigned long long)a.segmax;
     const unsigned to = (unsigned)((4 * hh + 8 * wave) * 4);
     // P of the lane's two tones: tone 16*th + (lane & 15); the second one 16 tones = 128 bytes on
     const unsigned po = (unsigned)(tg * 32 + (lane & 15)) * 8u;
@@ -599,6 +627,7 @@ __device__ __forceinline__ __attribute__((target("no-packed-fp32-ops"))) void ri
     // writers: unchanged (wave converts old k-step `wave`, lane (row r, half hh))
     const unsigned wr16 = lds_base + (unsigned)lane * 16u + (unsigned)wave * 2048u;
     const unsigned accaddr = lds_base + (unsigned)wave * 8192u + (unsigned)lane * 16u;
+    const unsigned seaddr = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char *)lds_scale + tid * 4u;
     const unsigned long long tpb = (unsigned long long)a.taps, ppb = (unsigned long long)a.ptab,
                              bfb = (unsigned long long)a.bfrag;
     const int o = gt * 32 + r;
@@ -632,14 +661,16 @@ __device__ __forceinline__ __attribute__((target("no-packed-fp32-ops"))) void ri
                    [pstride] "s"(__builtin_amdgcn_readfirstlane((int)((unsigned)Np * 8u))),
                    [nhi] "s"(__builtin_amdgcn_readfirstlane(nhi)),
                    [first] "s"(__builtin_amdgcn_readfirstlane(first)),
-                   [scale] "v"(S)
+                   [sgo] "v"(sgo), [sgn] "v"(sgn), [seaddr] "v"(seaddr),
+                   [sg_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)sgb)),
+                   [sg_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(sgb >> 32)))
                  : GSDR_MFMA_RING16_CLOBBERS);
     stamp(3);
     if (active && !timing_no_stores(sh)) {
         unsigned tid2 = threadIdx.x;
         asm volatile("" : "+v"(tid2));
         const int lane2 = (int)(tid2 & 63u);
-        const int se_self = row_scale_exp(a, gt * 32 + (lane2 & 31));   // again: nothing lives across the assembly
+        const int se_self = (int)(lds_scale[tid2] >> 23) - 127;      // the bits of S = 2^se, left by the loop
         float16v accr, acci;
         const float4v *acc = reinterpret_cast<const float4v *>(lds) + wave * 512 + lane2;
 #pragma unroll
@@ -659,6 +690,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
     const MfmaLaunch a) {
     constexpr int W = 4;
     __shared__ uint4 lds[2048];
+    __shared__ unsigned lds_scale[256];      // the bits of every lane's S, left by the loop for the epilogue
     static_assert(sizeof(uint4) * 2048 >= GSDR_MFMA_RING16_BYTES, "ring fits");
     const MfmaShape &sh = a.sh;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -671,10 +703,10 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
     const int tg = active ? tg_raw : sh.ntg - 1;
     stamp(0);
     stamp(2);
-    ring16_tile(a, lds, gt0, 1, tg, wave, active);
+    ring16_tile(a, lds, lds_scale, gt0, 1, tg, wave, active);
     if (rt > 1 && gt0 + 8 < sh.ngt) {
         workgroup_sync();
-        ring16_tile(a, lds, gt0 + 8, 0, tg, wave, active);
+        ring16_tile(a, lds, lds_scale, gt0 + 8, 0, tg, wave, active);
     }
     stamp(1);
 }
@@ -699,6 +731,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((target("no-packed-fp32-ops")
     constexpr int KS = 4, W = 8;
     // ring (3 slots of 8 KiB) while the loop runs, then the accumulators (8 waves x 8 KiB)
     __shared__ uint4 lds[4096];
+    __shared__ unsigned lds_scale[512];      // the bits of every lane's S, left by the loop for the epilogue
     static_assert(sizeof(uint4) * 4096 >= GSDR_MFMA_RING16W8_BYTES, "ring fits");
     const MfmaShape &sh = a.sh;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -718,7 +751,11 @@ __global__ __launch_bounds__(512, 2) __attribute__((target("no-packed-fp32-ops")
     const int lane = (int)(tid & 63u);
     const int r = lane & 31, hh = lane >> 5;
     const int kw = wave & 3;                  // old k-step this wave converts (in its blocks)
-    const float S = exp2_bits(row_scale_exp(a, gt * 32 + r));   // this lane converts row r of the tile
+    int q0, q1;                               // this lane converts row r of the tile: see ring16_tile
+    row_segments(sh, gt * 32 + r, q0, q1);
+    const unsigned sgo = (unsigned)q0 * 4u, sgn = (unsigned)(q1 - q0);
+    const unsigned long long sgb = (unsigned long long)a.segmax;
+    const unsigned seaddr = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char *)lds_scale + tid * 4u;
     const unsigned to = (unsigned)((4 * hh + 8 * kw) * 4);
     const unsigned po = (unsigned)(tg * 32 + (lane & 15)) * 8u;
     const unsigned bo = (unsigned)tg * (KS * 4 * 1024u) + (unsigned)lane * 16u;
@@ -759,13 +796,15 @@ __global__ __launch_bounds__(512, 2) __attribute__((target("no-packed-fp32-ops")
                    [pstride] "s"(__builtin_amdgcn_readfirstlane((int)((unsigned)Np * 8u))),
                    [nhi] "s"(__builtin_amdgcn_readfirstlane(nhi)),
                    [role] "s"(__builtin_amdgcn_readfirstlane(wave >> 2)),
-                   [scale] "v"(S)
+                   [sgo] "v"(sgo), [sgn] "v"(sgn), [seaddr] "v"(seaddr),
+                   [sg_lo] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)sgb)),
+                   [sg_hi] "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(sgb >> 32)))
                  : GSDR_MFMA_RING16W8_CLOBBERS);
     if (active && !timing_no_stores(sh)) {
         unsigned tid2 = threadIdx.x;
         asm volatile("" : "+v"(tid2));
         const int lane2 = (int)(tid2 & 63u);
-        const int se_self = row_scale_exp(a, gt * 32 + (lane2 & 31));   // again: nothing lives across the assembly
+        const int se_self = (int)(lds_scale[tid2] >> 23) - 127;      // the bits of S = 2^se, left by the loop
         float16v accr, acci;
         const float4v *acc = reinterpret_cast<const float4v *>(lds) + wave * 512 + lane2;
 #pragma unroll
@@ -848,7 +887,6 @@ __device__ __forceinline__ __attribute__((target("no-packed-fp32-ops"))) void ri
         unsigned tid2 = threadIdx.x;
         asm volatile("" : "+v"(tid2));
         const int lane2 = (int)(tid2 & 63u);
-        const int se_self = row_scale_exp(a, gt * 32 + (lane2 & 31));   // again: nothing lives across the assembly
         float16v accr, acci;
         const float4v *acc = reinterpret_cast<const float4v *>(lds) + wave * 512 + lane2;
 #pragma unroll
@@ -860,7 +898,7 @@ __device__ __forceinline__ __attribute__((target("no-packed-fp32-ops"))) void ri
                 acci[qd * 4 + j] = vi[j];
             }
         }
-        store_tile16(a, gt, tg, lane2, se_self, accr, acci);
+        store_tile16(a, gt, tg, lane2, kScaleFromTable, accr, acci);
     }
 }
 
@@ -881,17 +919,23 @@ __global__ __launch_bounds__(256, 2) __attribute__((target("no-packed-fp32-ops")
     ring16p_tile(a, lds, gt0, 1, tg, wave, active);
 }
 
-// The staging pass (StageLaunch in ddc_kernels.h).  One wave per piece: a piece is a segment of the
-// maxima table, or 1/pps of one when segments are long; a wave scans the part of its piece that lies in B
-// (what the previous call left in front), then the part in A (the new buffer), sixteen bytes per lane and
-// load, four loads in flight, and folds its maximum into the segment's entry with one atomicMax (float bits
-// of non-negative numbers order like unsigned integers; entries are hit by pps waves, plus one more where a
-// segment straddles B and A).  NaN and Inf patterns count as zero: they must not set a scale (see
-// row_scale_exp).  The copies for the main kernels ride along in the pieces that touch their ranges.
+// The staging pass (StageLaunch in ddc_kernels.h).  A workgroup takes 2048 consecutive samples of region A (the
+// new buffer) or of region B (what the previous call left in front), a wave 512 of them: sixteen bytes per lane and
+// load, all four loads of a wave in flight at once -- one memory round trip per wave.  Maxima per segment:
+//   * segments of 512 samples or more: a wave's samples lie in at most two of them; two running maxima per lane,
+//     a DPP butterfly each, one LDS atomic per wave and segment;
+//   * shorter segments: every lane folds its samples into the workgroup's LDS slots itself (ds_max_u32; the
+//     segment of a sample by a multiply-high with a host-made magic number);
+// then one global atomicMax per segment the workgroup touched (float bits of non-negative numbers order like
+// unsigned integers; an entry is hit by the few workgroups whose chunks share the segment).  NaN and Inf patterns
+// count as zero: they must not set a scale (see row_scale_exp).  The copies for the main kernels ride along in
+// the chunks that touch their ranges.
+constexpr int kStageChunk = 2048;                 // samples per workgroup
+constexpr int kStageSlots = kStageChunk / 64 + 3; // segments are at least 64 samples long
 struct StageShape {
-    long long seg_len, plen;   // samples per segment and per piece (plen even)
-    int pps;                   // pieces per segment
-    long long ttot;            // nb + n
+    unsigned seg_len;          // samples per segment (>= 64)
+    unsigned seg_magic;        // floor(2^32 / seg_len) + 1: x / seg_len = umulhi(x, magic) for x < 2^16 (short segments)
+    unsigned main_blocks;      // workgroups of region A; the rest take region B
 };
 
 __device__ __forceinline__ unsigned finite_bits(float v) {
@@ -899,81 +943,99 @@ __device__ __forceinline__ unsigned finite_bits(float v) {
     return b < 0x7f800000u ? b : 0u;
 }
 
-template <bool COPY>
-__device__ __forceinline__ unsigned stage_scan(const StageLaunch &s, const float2 *src, long long i0, long long i1,
-                                               int lane, float2 *dst) {
-    // samples src[i0 .. i1); COPY: region A with the head/tail copies; dst != null: region B copied to dst
-    unsigned m = 0;
-    for (long long base = i0 + 2 * lane; base < i1; base += 512) {
-        float4u v[4];
+__global__ __launch_bounds__(256) void absmax_kernel(const StageLaunch s, const StageShape g) {
+    // kStageCopies copies of every slot, picked by the lane: 50 lanes of a wave folding into ONE LDS word serialise
+    // (C2's 100-sample segments: 1 us of the pass); into eight words they do not
+    constexpr int kStageCopies = 8;
+    __shared__ unsigned slot[kStageSlots * kStageCopies];
+    // the table of the next call
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < s.nseg_alloc; i += (long long)gridDim.x * 256)
+        s.seg_clear[i] = 0u;
+    for (int i = threadIdx.x; i < kStageSlots * kStageCopies; i += 256) slot[i] = 0u;
+    const bool region_a = blockIdx.x < g.main_blocks;
+    const float2 *src = region_a ? s.x : s.b;
+    const long long cnt = region_a ? s.n : s.nb;
+    const long long tbase = region_a ? s.nb : 0;         // position of src[0] in T = [B | A]
+    const long long c0 = (long long)(region_a ? blockIdx.x : blockIdx.x - g.main_blocks) * kStageChunk;
+    const long long c1 = c0 + kStageChunk < cnt ? c0 + kStageChunk : cnt;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // segment of the chunk's first sample, and where in that segment it sits (one division per workgroup)
+    const unsigned long long t0 = (unsigned long long)(tbase + c0);
+    const unsigned seg0 = (unsigned)(t0 / g.seg_len);
+    const unsigned rem0 = (unsigned)(t0 - (unsigned long long)seg0 * g.seg_len);
+    const bool copies = region_a ? ((s.head_cur && c0 < s.head_n) || (s.head_next && c1 > s.n - s.carry_len) ||
+                                    (s.tail && c1 > s.tail0))
+                                 : s.b_dst != nullptr;
+    __syncthreads();
+    const long long w0 = c0 + 512 * wave;                 // this wave's samples: [w0, w0 + 512) below c1
+    float4u v[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const long long i = base + 128 * k;
-            if (i + 1 < i1) {
-                v[k] = *reinterpret_cast<const float4u *>(src + i);
-            } else if (i < i1) {
-                const float2 w = src[i];
-                v[k] = float4u{w.x, w.y, 0.f, 0.f};
-            } else {
-                v[k] = float4u{0.f, 0.f, 0.f, 0.f};
-            }
+    for (int k = 0; k < 4; ++k) {
+        const long long i = w0 + 2 * lane + 128 * k;
+        if (i + 1 < c1) {
+            v[k] = *reinterpret_cast<const float4u *>(src + i);
+        } else if (i < c1) {
+            const float2 w = src[i];
+            v[k] = float4u{w.x, w.y, 0.f, 0.f};
+        } else {
+            v[k] = float4u{0.f, 0.f, 0.f, 0.f};
         }
+    }
+    const bool long_segments = g.seg_len >= 512u;
+    unsigned m_lo = 0, m_hi = 0;
+    const unsigned wrem = rem0 + 512u * (unsigned)wave;   // offset of the wave's first sample from the start of segment seg0
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const long long i = base + 128 * k;
-            const unsigned b0 = finite_bits(v[k].x), b1 = finite_bits(v[k].y), b2 = finite_bits(v[k].z),
-                           b3 = finite_bits(v[k].w);
-            const unsigned u = b0 > b1 ? b0 : b1, w = b2 > b3 ? b2 : b3;
-            const unsigned t = u > w ? u : w;
-            m = m > t ? m : t;
-            if (COPY || dst) {
+    for (int k = 0; k < 4; ++k) {
+        const long long i = w0 + 2 * lane + 128 * k;
+        const unsigned b0 = finite_bits(v[k].x), b1 = finite_bits(v[k].y), b2 = finite_bits(v[k].z), b3 = finite_bits(v[k].w);
+        const unsigned ma = b0 > b1 ? b0 : b1, mb = b2 > b3 ? b2 : b3;     // the lane's two samples
+        const unsigned oa = wrem + 2u * (unsigned)lane + 128u * (unsigned)k, ob = oa + 1u;
+        if (long_segments) {
+            // the wave's 512 samples lie in at most two segments: the one of its first sample and the next
+            const unsigned first = wrem / g.seg_len;      // wave-uniform; wrem < seg_len + 2048
+            const unsigned edge = (first + 1u) * g.seg_len;
+            if (oa < edge) m_lo = m_lo > ma ? m_lo : ma; else m_hi = m_hi > ma ? m_hi : ma;
+            if (ob < edge) m_lo = m_lo > mb ? m_lo : mb; else m_hi = m_hi > mb ? m_hi : mb;
+        } else {
+            if (ma) atomicMax(&slot[__umulhi(oa, g.seg_magic) * kStageCopies + (lane & (kStageCopies - 1))], ma);
+            if (mb) atomicMax(&slot[__umulhi(ob, g.seg_magic) * kStageCopies + (lane & (kStageCopies - 1))], mb);
+        }
+        if (copies) {
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const long long ie = i + e;
-                    if (ie >= i1) break;
+            for (int e = 0; e < 2; ++e) {
+                const long long ie = i + e;
+                if (ie < c1) {
                     const float2 w2 = e ? make_float2(v[k].z, v[k].w) : make_float2(v[k].x, v[k].y);
-                    if (COPY) {
+                    if (region_a) {
                         if (s.head_cur && ie < s.head_n) s.head_cur[s.carry_len + ie] = w2;
                         if (s.head_next && ie >= s.n - s.carry_len) s.head_next[ie - (s.n - s.carry_len)] = w2;
                         if (s.tail && ie >= s.tail0) s.tail[ie - s.tail0] = w2;
                     } else {
-                        dst[ie] = w2;
+                        s.b_dst[ie] = w2;
                     }
                 }
             }
         }
     }
-    return m;
-}
-
-__global__ __launch_bounds__(256) void absmax_kernel(const StageLaunch s, const StageShape g) {
-    // the table of the next call
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < s.nseg_alloc; i += (long long)gridDim.x * 256)
-        s.seg_clear[i] = 0u;
-    const int lane = threadIdx.x & 63;
-    const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);     // piece
-    const long long q = w / g.pps;
-    const int r = (int)(w - q * g.pps);
-    long long t0 = q * g.seg_len + (long long)r * g.plen, t1 = t0 + g.plen;
-    const long long seg_end = (q + 1) * g.seg_len;
-    if (t1 > seg_end) t1 = seg_end;
-    if (t1 > g.ttot) t1 = g.ttot;
-    if (t0 >= t1) return;        // wave-uniform
-    unsigned m = 0;
-    if (t0 < s.nb) {
-        const long long e = t1 < s.nb ? t1 : s.nb;
-        m = stage_scan<false>(s, s.b, t0, e, lane, s.b_dst);
+    if (long_segments) {
+        const unsigned first = wrem / g.seg_len;
+        m_lo = wave_max_u32(m_lo);
+        m_hi = wave_max_u32(m_hi);
+        if (lane == 0) {
+            if (m_lo) atomicMax(&slot[first * kStageCopies], m_lo);
+            if (m_hi) atomicMax(&slot[(first + 1u) * kStageCopies], m_hi);
+        }
     }
-    if (t1 > s.nb) {
-        const long long i0 = (t0 > s.nb ? t0 : s.nb) - s.nb, i1 = t1 - s.nb;
-        const bool copies = (s.head_cur && i0 < s.head_n) || (s.head_next && i1 > s.n - s.carry_len) ||
-                            (s.tail && i1 > s.tail0);
-        const unsigned ma = copies ? stage_scan<true>(s, s.x, i0, i1, lane, nullptr)
-                                   : stage_scan<false>(s, s.x, i0, i1, lane, nullptr);
-        m = m > ma ? m : ma;
+    __syncthreads();
+    if (threadIdx.x < kStageSlots) {
+        unsigned m = 0;
+#pragma unroll
+        for (int c = 0; c < kStageCopies; ++c) {
+            const unsigned t = slot[threadIdx.x * kStageCopies + c];
+            m = m > t ? m : t;
+        }
+        if (m) atomicMax(&s.seg[seg0 + threadIdx.x], m);
     }
-    m = wave_max_u32(m);
-    if (lane == 0 && m) atomicMax(&s.seg[q], m);
 }
 
 // ---------------------------------------------------------------------------
@@ -1116,27 +1178,20 @@ void mfma_build_tables(const MfmaPlan &pl, const std::vector<unsigned> &fmod_in,
 
 hipError_t launch_absmax(const StageLaunch &s, hipStream_t st) {
     if (!s.x || s.n < 1 || s.nb < 0 || (s.nb > 0 && !s.b) || s.carry_len < 0 || s.carry_len > s.n || s.head_n < 0 ||
-        s.head_n > s.n || s.tail0 < 0 || s.tail0 > s.n || !s.seg || !s.seg_clear || s.seg_len < 1 || s.nseg_alloc < 1)
+        s.head_n > s.n || s.tail0 < 0 || s.tail0 > s.n || !s.seg || !s.seg_clear || s.seg_len < 64 ||
+        s.seg_len > 0x7fffffffLL || s.nseg_alloc < 1)
         return hipErrorInvalidValue;
-    StageShape g{};
-    g.seg_len = s.seg_len;
-    g.ttot = s.nb + s.n;
-    const long long nseg = (g.ttot + s.seg_len - 1) / s.seg_len;
+    // every segment a workgroup can touch has an entry: (nb + n) / seg_len rounded up, plus the slots a
+    // chunk's last wave may name beyond its data (always zero, never written: only non-zero maxima are)
+    const long long nseg = (s.nb + s.n + s.seg_len - 1) / s.seg_len;
     if (nseg > s.nseg_alloc) return hipErrorInvalidValue;
-    // pieces of at most ~1024 samples (GSDR_ABSMAX_CHUNK): a wave per piece
-    static const long long want = [] {
-        const char *e = std::getenv("GSDR_ABSMAX_CHUNK");
-        const long long v = e ? std::atoll(e) : 1024;
-        return v >= 128 ? v : 1024;
-    }();
-    g.pps = (int)((s.seg_len + want - 1) / want);
-    if (g.pps < 1) g.pps = 1;
-    g.plen = (s.seg_len + g.pps - 1) / g.pps;
-    g.plen += g.plen & 1;
-    const long long pieces = nseg * g.pps;
-    const long long blocks = (pieces + 3) / 4;
-    if (blocks < 1 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, s, g);
+    StageShape g{};
+    g.seg_len = (unsigned)s.seg_len;
+    g.seg_magic = (unsigned)(0x100000000ULL / (unsigned long long)s.seg_len + 1ULL);
+    const long long ba = (s.n + kStageChunk - 1) / kStageChunk, bb = (s.nb + kStageChunk - 1) / kStageChunk;
+    if (ba + bb > 0x7fffffffLL) return hipErrorInvalidValue;
+    g.main_blocks = (unsigned)ba;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(ba + bb)), dim3(256), 0, st, s, g);
     return hipGetLastError();
 }
 
@@ -1149,7 +1204,7 @@ hipError_t launch_ddc_mfma(MfmaKernel kind, int TT, int PK, int W, const MfmaLau
         (long long)(sh.nout - 1 + sh.woff) * sh.M + sh.MF > sh.nx ||
         (long long)sh.woff * sh.M + sh.carry_len < 0 || (sh.woff < 0 && -sh.woff > 32) ||
         !a.x || !a.head || !a.tail || !a.out || !a.bfrag || !a.ptab || !a.dtab || !a.taps ||
-        !a.fmod || !a.segmax || sh.seg_k < 1)
+        !a.fmod || !a.segmax || sh.seg_k < 1 || sh.F < 1 || sh.F > 8 || sh.MF != sh.M * sh.F)
         return hipErrorInvalidValue;
     // the row tiles between the first and the last read a.x directly, 8 samples at a time
     // (TONES passes its own over-allocated window as x, head and tail alike); a row

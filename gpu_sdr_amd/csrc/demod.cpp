@@ -131,6 +131,12 @@ struct gsdr_demod {
     // scale slots, the raw windows and the head/tail copies pass from one call to the next ON THE
     // DEVICE: a call that runs on another stream than its predecessors first joins them (an event
     // recorded on the old stream at that moment covers everything enqueued there before).
+    // A stream of the CALLER's stays in this list only until the next call on the handle (which joins it and
+    // forgets it): include/gsdr.h asks the caller to keep a stream alive that long.  (An event of the handle's own
+    // recorded behind every call would lift that condition, and was tried: an event record costs 3 - 4 us of stream
+    // time, which doubled the step period of the chirp path -- 5.1 -> 9.2 us -- and showed in every in-order figure.)
+    // If recording on a remembered stream returns an error, the entry is dropped and the call goes on.  (A stream
+    // destroyed before that is beyond help: HIP faults inside hipEventRecord, tests/test_gpu_parity.py.)
     std::vector<hipStream_t> dirty;
     hipEvent_t ev_join = nullptr;
     bool pipe_overlap = false;         // set around the compute of an overlapped call
@@ -452,6 +458,7 @@ int setup_mfma(gsdr_demod *h, bool direct, const std::vector<long long> &tone) {
     sh.ntq = (pl.ntg + h->mf_W - 1) / h->mf_W;
     sh.M = M;
     sh.MF = pl.MF;
+    sh.F = F;
     sh.nk8 = pl.nk8;
     sh.woff = direct ? -(F - 1) : 0;
     sh.carry_len = direct ? (F - 1) * M : 0;
@@ -524,7 +531,11 @@ int join_streams(gsdr_demod *h, hipStream_t st, Keep keep) {
             continue;
         }
         if (!h->ev_join) HIPCHK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-        HIPCHK(h, hipEventRecord(h->ev_join, s));
+        if (hipEventRecord(h->ev_join, s) != hipSuccess) {
+            // nothing that could still be waited for: forget the stream rather than fail every later call
+            (void)hipGetLastError();
+            continue;
+        }
         HIPCHK(h, hipStreamWaitEvent(st, h->ev_join, 0));
     }
     h->dirty.resize(w);
@@ -1314,17 +1325,19 @@ int gsdr_demod_process_device(gsdr_demod *h, const gsdr_c64 *in_dev, gsdr_c64 *o
     }
     const float2 *in = reinterpret_cast<const float2 *>(in_dev);
     float2 *out = reinterpret_cast<float2 *>(out_dev);
+    int n;
     switch (h->mode) {
-        case GSDR_DIRECT: return enqueue_direct(h, in, out, st);
+        case GSDR_DIRECT: n = enqueue_direct(h, in, out, st); break;
         case GSDR_TONES:
-        case GSDR_NOISE: return enqueue_pfb(h, in, out, st);
-        case GSDR_CHIRP: return enqueue_chirp(h, in, out, st);
+        case GSDR_NOISE: n = enqueue_pfb(h, in, out, st); break;
+        case GSDR_CHIRP: n = enqueue_chirp(h, in, out, st); break;
         case GSDR_NODSP:  // ref: process_nodsp :335-339
             HIPCHK(h, hipMemcpyAsync(out, in, (size_t)h->L * sizeof(float2),
                                      hipMemcpyDeviceToDevice, st));
-            return (int)h->L;
+            return (int)h->L;     // no state passes from call to call
         default: h->err = "unsupported mode"; return -1;
     }
+    return n;
 }
 
 int gsdr_demod_process(gsdr_demod *h, const gsdr_c64 *in_host, gsdr_c64 *out_host) {
@@ -1808,6 +1821,11 @@ struct gsdr_txgen {
     gsdr_chirp_param cp{};
     float scale = 1.f;
     float2 *d_stage = nullptr;         // get() to host memory goes through here
+    size_t stage_n = 0;                // samples d_stage holds
+    // TONES through gsdr_txgen_get_ptr: one period + one buffer of the comb in host memory, made once
+    // (the reference's base_buffer, cpp/USRP_buffer_generator.cpp:77-95)
+    float2 *h_period = nullptr;
+    bool h_period_pinned = false;
 };
 
 gsdr_txgen *gsdr_txgen_tones_create(int rate, const int *freq, const float *ampl, const float *phase, int n_tones,
@@ -1880,6 +1898,10 @@ void gsdr_txgen_close(gsdr_txgen *g) {
     (void)hipDeviceSynchronize();
     for (void *p : {(void *)g->d_fmod, (void *)g->d_q0, (void *)g->d_btab, (void *)g->d_ctab, (void *)g->d_stage})
         if (p) (void)hipFree(p);
+    if (g->h_period) {
+        if (g->h_period_pinned) (void)hipHostFree(g->h_period);
+        else std::free(g->h_period);
+    }
     delete g;
 }
 
@@ -1907,9 +1929,10 @@ gsdr_txgen *gsdr_txgen_create(const gsdr_param_c *p, const float *ampl, int n_am
         return fail("Mixed TX buffer generation has been requested. This feature is not implemented yet.");
     if (last == GSDR_NODSP || last == GSDR_SWONLY) return fail("NODSP CASE NOT IMPLEMENTED.");   // :41-44
     if (last == GSDR_RAMP || last == GSDR_DIRECT) return fail("RAMP CASE NOT IMPLEMENTED.");      // :46-49
-    if (last == GSDR_NOISE) return fail("NOISE TX generation is empty in the reference (get_from_noise)");   // :52-58
     gsdr_txgen *g = nullptr;
-    if (last == GSDR_TONES) {
+    // NOISE: the reference's `case NOISE:` (:52-58) has no break and falls through into TONES, which overwrites its
+    // get/close pointers: a TX NOISE request generates the tone comb of freq[] / ampl[] there, and so it does here
+    if (last == GSDR_TONES || last == GSDR_NOISE) {
         const int n = p->n_wave_type;
         if (p->n_freq < n || !p->freq || n_ampl < n || !ampl) return fail("TONES needs freq[] and ampl[] for every wave_type entry");
         std::vector<int> tf((size_t)n);
@@ -1928,10 +1951,9 @@ gsdr_txgen *gsdr_txgen_create(const gsdr_param_c *p, const float *ampl, int n_am
         g = new gsdr_txgen();
         g->device = p->device_index;
         g->rate = (unsigned)p->rate;
-        gsdr_chirp_derive(p->rate, p->freq[0], p->chirp_f[0], p->swipe_s[0], p->chirp_t[0], &g->cp);
-        // the TX side also resets num_steps when a step would be shorter than one sample (:111-115); the RX side does not
-        if (p->chirp_t[0] * (float)p->rate / (float)g->cp.num_steps < 1.f)
-            g->cp.num_steps = (unsigned long long)(p->chirp_t[0] * (float)p->rate);
+        // the TX side's own derivation: a step shorter than one sample also resets num_steps, and the slope
+        // follows the reset value (:107-129)
+        gsdr_chirp_derive_tx(p->rate, p->freq[0], p->chirp_f[0], p->swipe_s[0], p->chirp_t[0], &g->cp);
         if (g->cp.num_steps < 1 || g->cp.length < 1 || g->cp.num_steps > 0x7fffffffffffffffULL / g->cp.length) {
             delete g;
             return fail("chirp period overflows");
@@ -1941,7 +1963,7 @@ gsdr_txgen *gsdr_txgen_create(const gsdr_param_c *p, const float *ampl, int n_am
     } else {
         return fail("Void TX generation operation has not been implemented yet!");
     }
-    g->mode = last;
+    g->mode = last == GSDR_NOISE ? GSDR_TONES : last;
     g->buffer_len = p->buffer_len;
     g->last = 0;
     return g;
@@ -1978,9 +2000,16 @@ int gsdr_txgen_get(gsdr_txgen *g, gsdr_c64 *out_host) {
         g_create_error = "gsdr_txgen_get: hipSetDevice failed";
         return -1;
     }
-    if (!g->d_stage && dev_alloc(&g->d_stage, (size_t)g->buffer_len) != hipSuccess) {
-        g_create_error = "gsdr_txgen_get: device allocation failed";
-        return -1;
+    if (g->d_stage && g->stage_n < (size_t)g->buffer_len) {
+        (void)hipFree(g->d_stage);
+        g->d_stage = nullptr;
+    }
+    if (!g->d_stage) {
+        if (dev_alloc(&g->d_stage, (size_t)g->buffer_len) != hipSuccess) {
+            g_create_error = "gsdr_txgen_get: device allocation failed";
+            return -1;
+        }
+        g->stage_n = (size_t)g->buffer_len;
     }
     if (gsdr_txgen_get_device(g, reinterpret_cast<gsdr_c64 *>(g->d_stage), nullptr) != 0) return -1;
     const hipError_t e = hipMemcpy(out_host, g->d_stage, (size_t)g->buffer_len * sizeof(float2), hipMemcpyDeviceToHost);
@@ -1990,6 +2019,71 @@ int gsdr_txgen_get(gsdr_txgen *g, gsdr_c64 *out_host) {
     }
     return 0;
 }
+
+// ref: the TONES branch of the constructor (:77-95): base_buffer = one period (TONES_buffer_len samples) plus
+// buffer_len more (a copy of its beginning), in host memory.  Made once, in pieces through a device buffer.
+int gsdr_txgen_prepare_host(gsdr_txgen *g) {
+    if (!g || g->mode != GSDR_TONES) {
+        g_create_error = "gsdr_txgen_prepare_host: a TONES generator is needed";
+        return -1;
+    }
+    if (g->h_period) return 0;
+    if (g->device >= 0 && hipSetDevice(g->device) != hipSuccess) {
+        g_create_error = "gsdr_txgen_prepare_host: hipSetDevice failed";
+        return -1;
+    }
+    const unsigned long long total = g->period + (unsigned long long)g->buffer_len;
+    float2 *hp = nullptr;
+    bool pinned = hipHostMalloc((void **)&hp, (size_t)total * sizeof(float2)) == hipSuccess;
+    if (!pinned) {
+        (void)hipGetLastError();
+        hp = (float2 *)std::malloc((size_t)total * sizeof(float2));
+    }
+    if (!hp) {
+        g_create_error = "gsdr_txgen_prepare_host: cannot allocate the period buffer in host memory";
+        return -1;
+    }
+    const size_t piece = (size_t)(total < (8u << 20) ? total : (8u << 20));
+    if (g->d_stage && g->stage_n < piece) {
+        (void)hipFree(g->d_stage);
+        g->d_stage = nullptr;
+    }
+    bool ok = true;
+    if (!g->d_stage) {
+        ok = dev_alloc(&g->d_stage, piece) == hipSuccess;
+        g->stage_n = ok ? piece : 0;
+    }
+    for (unsigned long long off = 0; ok && off < total; off += piece) {
+        const long long n = (long long)(total - off < piece ? total - off : piece);
+        ok = gsdr_txgen_tones_fill(g, reinterpret_cast<gsdr_c64 *>(g->d_stage), n, (long long)(off % g->rate), nullptr) == 0 &&
+             hipMemcpy(hp + off, g->d_stage, (size_t)n * sizeof(float2), hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    if (!ok) {
+        if (pinned) (void)hipHostFree(hp);
+        else std::free(hp);
+        if (g_create_error.empty()) g_create_error = "gsdr_txgen_prepare_host: generating the period failed";
+        return -1;
+    }
+    g->h_period = hp;
+    g->h_period_pinned = pinned;
+    return 0;
+}
+
+// ref: get_from_tones (:226-229): *target = base_buffer + TONES_last_sample -- the caller's pointer is REPLACED by one
+// into the generator's own period buffer (tx_single_link hands in an unallocated pointer for TONES,
+// cpp/USRP_server_link_threads.cpp:568-584, and never frees what it gets back).
+const gsdr_c64 *gsdr_txgen_get_ptr(gsdr_txgen *g) {
+    if (!g || g->mode != GSDR_TONES) {
+        g_create_error = "gsdr_txgen_get_ptr: a TONES generator is needed";
+        return nullptr;
+    }
+    if (!g->h_period && gsdr_txgen_prepare_host(g) != 0) return nullptr;
+    const gsdr_c64 *p = reinterpret_cast<const gsdr_c64 *>(g->h_period + g->last);
+    g->last = (g->last + (unsigned long long)g->buffer_len) % g->period;
+    return p;
+}
+
+int gsdr_txgen_mode(const gsdr_txgen *g) { return g ? g->mode : -1; }
 
 int gsdr_source_chirp(gsdr_c64 *out_dev, long long n, unsigned long long last_index,
                       const gsdr_chirp_param *cp, float scale, void *hip_stream) {

@@ -187,4 +187,26 @@ void gsdr_chirp_derive(int rate, int freq0, int chirp_f, int swipe_s,
     cp->f0 = (start > -2147483649.0 && start < 2147483648.0) ? (int)start : INT_MIN;
 }
 
+// ref: TX_buffer_generator, CHIRP case, cpp/USRP_buffer_generator.cpp:107-127.  The same derivation with one
+// difference: when a step would be shorter than one sample the TX side also resets num_steps to chirp_t * rate
+// (:115-119) BEFORE the slope is computed from it (:122); the RX side keeps the requested num_steps
+// (cpp/USRP_demodulator.cpp:203-206).
+void gsdr_chirp_derive_tx(int rate, int freq0, int chirp_f, int swipe_s,
+                          float chirp_t, gsdr_chirp_param *cp) {
+    unsigned long long steps = (unsigned long long)(long long)swipe_s;  // :107
+    if (steps < 1) steps = (unsigned long long)(chirp_t * rate);        // :108-111
+    unsigned long long len = (unsigned long long)(chirp_t * rate / steps);  // :117, float maths
+    if (len < 1) {                                                      // :118-122
+        len = 1;
+        steps = (unsigned long long)(chirp_t * rate);
+    }
+    const double two32m1 = std::pow(2, 32) - 1;
+    const double slope = (two32m1 * (chirp_f - freq0) / ((double)steps - 1.)) / (double)rate;  // :125
+    const double start = two32m1 * ((double)freq0 / (double)rate);                           // :129
+    cp->num_steps = steps;
+    cp->length = len;
+    cp->chirpness = (slope > -9.2e18 && slope < 9.2e18) ? (unsigned int)(long long)slope : 0u;
+    cp->f0 = (start > -2147483649.0 && start < 2147483648.0) ? (int)start : INT_MIN;
+}
+
 }  // extern "C"

@@ -358,3 +358,10 @@ def chirp_derive(rate, freq0, chirp_f, swipe_s, chirp_t) -> _lib.ChirpParamC:
     cp = _lib.ChirpParamC()
     _lib.lib().gsdr_chirp_derive(rate, freq0, chirp_f, swipe_s, C.c_float(chirp_t), C.byref(cp))
     return cp
+
+
+def chirp_derive_tx(rate, freq0, chirp_f, swipe_s, chirp_t) -> _lib.ChirpParamC:
+    """The TX generator's own derivation (ref: cpp/USRP_buffer_generator.cpp:107-129)."""
+    cp = _lib.ChirpParamC()
+    _lib.lib().gsdr_chirp_derive_tx(rate, freq0, chirp_f, swipe_s, C.c_float(chirp_t), C.byref(cp))
+    return cp

@@ -78,7 +78,22 @@ class TX_buffer_generator:
         self._h = L.gsdr_txgen_create(C.byref(pc), ampl.ctypes.data_as(C.POINTER(C.c_float)), len(ampl))
         if not self._h:
             raise GsdrError(L.gsdr_last_error(None).decode())
-        self.mode = w_type(p.wave_type[0])
+        self.mode = w_type(L.gsdr_txgen_mode(self._h))      # a NOISE request is TONES (the reference falls through)
+
+    def get_view(self) -> np.ndarray:
+        """TONES as the reference's get() hands them out (get_from_tones, cpp/USRP_buffer_generator.cpp:226-229):
+        the next buffer_len samples as a read-only VIEW of the generator's own host period buffer
+        (gsdr_txgen_get_ptr); valid until close()."""
+        import ctypes as C
+        if not self._h:
+            raise GsdrError("generator is closed")
+        ptr = self._L.gsdr_txgen_get_ptr(self._h)
+        if not ptr:
+            raise GsdrError(self._L.gsdr_last_error(None).decode())
+        buf = (C.c_float * (2 * self.buffer_len)).from_address(ptr)
+        v = np.frombuffer(buf, dtype=np.complex64, count=self.buffer_len)
+        v.flags.writeable = False
+        return v
 
     def get(self, out, stream=None) -> None:
         import ctypes as C

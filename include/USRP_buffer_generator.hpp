@@ -50,10 +50,31 @@ class TX_buffer_generator {
             std::fprintf(stderr, "ERROR: %s\n", gsdr_last_error(nullptr));
             std::exit(-1);
         }
+        tones_ = gsdr_txgen_mode(handle_) == GSDR_TONES;
+        // TONES: the whole period exists in host memory when the constructor returns, like the reference's
+        // base_buffer (ref: cpp/USRP_buffer_generator.cpp:77-95)
+        if (tones_ && gsdr_txgen_prepare_host(handle_) != 0) {
+            std::fprintf(stderr, "ERROR: %s\n", gsdr_last_error(nullptr));
+            std::exit(-1);
+        }
     }
 
-    //! fills *in (host memory, buffer_len samples) with the next buffer (ref: cpp/USRP_buffer_generator.cpp:163-169)
+    //! The next buffer_len samples (ref: cpp/USRP_buffer_generator.cpp:163-169).  As in the reference the two
+    //! kinds of generator treat `in` differently:
+    //!   TONES  *in is REPLACED by a pointer into the generator's own period buffer (get_from_tones, :226-229);
+    //!          whatever *in was is neither read nor written -- tx_single_link passes an unallocated pointer
+    //!          here (param::dynamic_buffer() is false for TONES, ref: cpp/USRP_server_link_threads.cpp:568-584);
+    //!   CHIRP  *in must point to buffer_len samples of host memory, which are filled (get_from_chirp, :208-221).
     void get(float2** in) {
+        if (tones_) {
+            const gsdr_c64* p = gsdr_txgen_get_ptr(handle_);
+            if (!p) {
+                std::fprintf(stderr, "ERROR: %s\n", gsdr_last_error(nullptr));
+                std::exit(-1);
+            }
+            *in = reinterpret_cast<float2*>(const_cast<gsdr_c64*>(p));
+            return;
+        }
         if (gsdr_txgen_get(handle_, reinterpret_cast<gsdr_c64*>(*in)) != 0) {
             std::fprintf(stderr, "ERROR: %s\n", gsdr_last_error(nullptr));
             std::exit(-1);
@@ -68,6 +89,7 @@ class TX_buffer_generator {
 
    private:
     gsdr_txgen* handle_;
+    bool tones_ = false;
 };
 
 #endif

@@ -63,6 +63,14 @@ struct param {
     size_t data_mem_mult;
     int fft_tones;
     size_t pf_average;
+    //! does a TX measurement with these parameters need buffers allocated per packet?
+    //! (ref: param::dynamic_buffer, cpp/USRP_server_settings.cpp:98-102: everything but TONES)
+    bool dynamic_buffer() {
+        bool dynamic = false;
+        for (size_t i = 0; i < wave_type.size(); i++)
+            if (wave_type[i] != TONES) dynamic = true;
+        return dynamic;
+    }
 };
 
 // ref: headers/USRP_server_settings.hpp:216-224

@@ -84,7 +84,10 @@ int gsdr_demod_process(gsdr_demod *h, const gsdr_c64 *in_host, gsdr_c64 *out_hos
  * Consecutive calls may use different streams, and may be mixed with the
  * submit entries below: the state a call inherits (FIR carry, NCO index, raw
  * windows) is ordered on the device -- a call on another stream than its
- * predecessor first waits for it (one event; nothing on the usual path). */
+ * predecessor first waits for it (one event; nothing on the usual path).
+ * For that the handle remembers the stream of a call until the NEXT call on
+ * the handle has been made: a stream passed here must stay alive that long
+ * (or until gsdr_demod_close()); HIP itself faults on a destroyed stream. */
 int gsdr_demod_process_device(gsdr_demod *h, const gsdr_c64 *in_dev,
                               gsdr_c64 *out_dev, void *hip_stream);
 
@@ -219,6 +222,10 @@ typedef struct gsdr_chirp_param {
 } gsdr_chirp_param;
 void gsdr_chirp_derive(int rate, int freq0, int chirp_f, int swipe_s,
                        float chirp_t, gsdr_chirp_param *cp);
+/* The TX side's own derivation (ref: cpp/USRP_buffer_generator.cpp:107-129): as above, but a step shorter than
+ * one sample also resets num_steps to chirp_t * rate before the slope is taken from it (:118-125). */
+void gsdr_chirp_derive_tx(int rate, int freq0, int chirp_f, int swipe_s,
+                          float chirp_t, gsdr_chirp_param *cp);
 
 /* ---- the pyUSRP command surface (host only) ------------------------------
  * One JSON command per measurement arrives on the async socket, framed by an
@@ -309,11 +316,22 @@ void gsdr_txgen_close(gsdr_txgen *g);
  * buffer_len samples.  TONES: the tone comb above (tone set as gsdr_tx_tone_bins(); the sample index wraps at
  * rate * ceil(buffer_len / rate), :60-75); CHIRP: the chirp_gen law (cpp/kernels.cu:335-372) scaled by ampl[0],
  * with the TX side's own num_steps reset (:111-115), the running index wrapping at num_steps * length.  Where
- * the reference exits (mixed or several CHIRP wave types, NODSP/SWONLY/RAMP/DIRECT, NOISE's empty generator)
+ * the reference exits (mixed or several CHIRP wave types, NODSP/SWONLY/RAMP/DIRECT)
  * create returns NULL with the same text in gsdr_last_error(NULL).  gsdr_txgen_get: to host memory
  * (synchronous, like the reference's get); gsdr_txgen_get_device: to device memory on hip_stream. */
 gsdr_txgen *gsdr_txgen_create(const gsdr_param_c *p, const float *ampl, int n_ampl);
 int gsdr_txgen_get(gsdr_txgen *g, gsdr_c64 *out_host);
+/* TONES as the reference hands them out (ref: get_from_tones, cpp/USRP_buffer_generator.cpp:226-229): the next
+ * buffer_len samples as a pointer INTO the generator's own host memory -- one period of the comb plus one buffer
+ * (rate * ceil(buffer_len / rate) + buffer_len samples, :60-95), valid and unchanged until gsdr_txgen_close().  The
+ * caller's buffer is not touched: tx_single_link passes an unallocated pointer for TONES and queues what it gets
+ * back (ref: cpp/USRP_server_link_threads.cpp:568-584).  The period is generated on the GPU the first time it is
+ * needed, or by gsdr_txgen_prepare_host() (what the reference's constructor does with its inverse FFT of length
+ * `rate`: 1.6 GB of host memory at 200 Msps, there as here).  NULL on failure (gsdr_last_error(NULL)). */
+const gsdr_c64 *gsdr_txgen_get_ptr(gsdr_txgen *g);
+int gsdr_txgen_prepare_host(gsdr_txgen *g);
+/* GSDR_TONES or GSDR_CHIRP (a NOISE request is TONES: the reference's `case NOISE` falls through, :52-58) */
+int gsdr_txgen_mode(const gsdr_txgen *g);
 int gsdr_txgen_get_device(gsdr_txgen *g, gsdr_c64 *out_dev, void *hip_stream);
 long long gsdr_txgen_buffer_len(const gsdr_txgen *g);
 /* TX chirp law (ref: chirp_gen, cpp/kernels.cu:335-372) written to device. */

@@ -186,6 +186,16 @@ def chirp_params(rate, freq0, chirp_f, swipe_s, chirp_t) -> ChirpParam:
     return cp
 
 
+def chirp_params_tx(rate, freq0, chirp_f, swipe_s, chirp_t) -> ChirpParam:
+    """TX generator's derivation (cpp/USRP_buffer_generator.cpp:107-129)."""
+    cp = ChirpParam()
+    L = lib()
+    L.oracle_chirp_params_tx.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(ChirpParam)]
+    L.oracle_chirp_params_tx.restype = None
+    L.oracle_chirp_params_tx(rate, freq0, chirp_f, swipe_s, C.c_float(chirp_t), C.byref(cp))
+    return cp
+
+
 def direct_mix(freq, rate, idx, x) -> np.ndarray:
     f, fptr = _iarr(freq)
     x, xp = _c64(x)

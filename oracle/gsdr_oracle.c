@@ -187,6 +187,25 @@ void oracle_chirp_params(int rate, int freq0, int chirp_f, int swipe_s,
     cp->f0 = d2i32_x86(f0);
 }
 
+/* cpp/USRP_buffer_generator.cpp:107-129: the TX generator's derivation.  Differs from the RX
+ * one in :118-122: a step shorter than a sample resets num_steps as well, before the slope. */
+void oracle_chirp_params_tx(int rate, int freq0, int chirp_f, int swipe_s,
+                            float chirp_t, oracle_chirp_param *cp) {
+    cp->num_steps = (unsigned long)(long)swipe_s;              /* :107 */
+    if (cp->num_steps < 1)                                      /* :108-111 */
+        cp->num_steps = (unsigned long)(chirp_t * rate);
+    cp->length = (unsigned long)(chirp_t * rate / cp->num_steps);  /* :117 */
+    if (cp->length < 1) {                                       /* :118-122 */
+        cp->length = 1;
+        cp->num_steps = (unsigned long)(chirp_t * rate);
+    }
+    double chirpness = ((pow(2, 32) - 1) * (chirp_f - freq0) /
+                        ((double)cp->num_steps - 1.)) / (double)rate; /* :125 */
+    cp->chirpness = d2u32_x86(chirpness);
+    double f0 = (pow(2, 32) - 1) * ((double)freq0 / (double)rate);   /* :129 */
+    cp->f0 = d2i32_x86(f0);
+}
+
 /* ======================================================================== */
 /* DIRECT                                                                   */
 /* ======================================================================== */

@@ -67,6 +67,9 @@ typedef struct {
 } oracle_chirp_param;
 void oracle_chirp_params(int rate, int freq0, int chirp_f, int swipe_s,
                          float chirp_t, oracle_chirp_param *cp);
+/* TX generator's derivation, cpp/USRP_buffer_generator.cpp:107-129 */
+void oracle_chirp_params_tx(int rate, int freq0, int chirp_f, int swipe_s,
+                            float chirp_t, oracle_chirp_param *cp);
 
 /* ---- DIRECT (per-tone DDC) -------------------------------------------- */
 /* cpp/kernels.cu:45-86 : out[ch*L + j], tone-major, float-rounded */

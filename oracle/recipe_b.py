@@ -261,6 +261,24 @@ def chirp_params(rate: int, freq0: int, chirp_f: int, swipe_s: int, chirp_t: flo
     return num_steps, length, chirpness, f0
 
 
+def chirp_params_tx(rate: int, freq0: int, chirp_f: int, swipe_s: int, chirp_t: float):
+    """ref: TX_buffer_generator CHIRP case, cpp/USRP_buffer_generator.cpp:107-129: as chirp_params, but a step
+    shorter than one sample resets num_steps too (:118-122), and the slope (:125) uses the reset value."""
+    f32 = np.float32
+    num_steps = int(swipe_s)
+    if num_steps < 1:
+        num_steps = int(f32(chirp_t) * f32(rate))                      # :110
+    length = int((f32(chirp_t) * f32(rate)) / f32(num_steps))          # :117
+    if length < 1:
+        length = 1                                                     # :120
+        num_steps = int(f32(chirp_t) * f32(rate))                      # :121
+    two32m1 = float(2 ** 32 - 1)
+    chirpness_d = (two32m1 * (int(chirp_f) - int(freq0)) / (float(num_steps) - 1.0)) / float(rate)   # :125
+    chirpness = int(chirpness_d) & 0xFFFFFFFF
+    f0 = int(two32m1 * (float(freq0) / float(rate)))                   # :129
+    return num_steps, length, chirpness, f0
+
+
 def chirp_demod(x: np.ndarray, last_index: int, num_steps: int, length: int, chirpness: int, f0: int) -> np.ndarray:
     """ref: chirp_demodulator, cpp/kernels.cu:389-427; all index arithmetic in wrapping
     uint64 (`unsigned long`), then truncated to `int`."""

@@ -372,18 +372,24 @@ def hdr_comb(N, rate, L, span_db, rng, start):
                          ids=["M100", "M1000"])
 def test_direct_high_dynamic_range_comb(cuda_device, gsdr_lib, oracle_mod, monkeypatch, impl, span_db, shape):
     """A comb whose tones span 40 / 60 dB, against the fp64 oracle.  The matrix-core engine
-    carries ~22 bits relative to the buffer's absolute maximum (one power-of-two scale per
-    buffer, fp16 hi/lo split), the fp32 engines 24 relative to each product: the weakest
-    tones are where they could differ most.  Errors are recorded per engine (strong half /
-    weak half of the comb) in the margin file.
+    carries ~22 bits relative to the largest sample of each output row's window (one power-of-two
+    scale per row, fp16 hi/lo split), the fp32 engines 24 relative to each product: the weakest
+    tones are where they could differ most.
 
-    Measured (profiles/r02_parity_margins.json): at 40 dB both engines stay under 1.6e-6 per
-    tone; at 60 dB BOTH engines sit at 1.0e-5 .. 1.3e-5 on the weakest tones (packed-FP32 VALU
-    1.27e-5 / 1.13e-5, matrix cores 1.25e-5 / 0.97e-5): a tone 60 dB under the strongest is at
-    the noise floor of ANY fp32 evaluation of this sum (6e-8 x the strong tones' products x
-    1000), the reference's own float mix + cuBLAS Cgemm included, so there the per-tone bar is
-    not a property of the engine.  The asserted bound at 60 dB is 3e-5 per tone plus 1e-6 over
-    all tones together (error against the comb's total power), at 40 dB the bar itself."""
+    The bar is 1e-5 per tone.  A tone 60 dB under the strongest sits at the noise floor of any
+    fp32 evaluation of this sum, so the test also evaluates the REFERENCE'S OWN ARITHMETIC on the
+    same buffers -- oracle/recipe_b.py with complex64 accumulation: double sincos mix stored as
+    float (ref: cpp/kernels.cu:72-83), then the fp32 Cgemm + Caxpy order (ref: cpp/fir.cu:44-62) --
+    and measures it against the same fp64 oracle.  Per tone the HIP path must stay within the larger
+    of 1e-5 and 3 x the restatement's own error, and below 1.5e-5 outright (round 2 asserted a flat 3e-5
+    at 60 dB).  Both errors and their largest per-tone ratio go to the margin file.  What the evidence says
+    (profiles/r03_parity_margins.json): at 40 dB everything is below 1.6e-6.  At 60 dB the two weakest tones
+    of the M100 shape come out at 1.00e-5 and 1.26e-5 on BOTH HIP engines while the fp32 restatement itself
+    is at 0.4e-5 .. 0.97e-5 there: the engines carry 2 - 2.6 x the noise of the reference's order of
+    operations -- they mix in fp32 (a table phasor times a block phasor: two or three roundings per product;
+    the matrix cores 22-bit operands), where the reference mixes in double and rounds once -- so at 60 dB
+    down the per-tone bar is missed by up to 26 % on those tones; it is not, as round 2 argued, a floor the
+    reference's own arithmetic shares."""
     N, rate, M, F, L = shape
     monkeypatch.setenv("GSDR_DDC_MFMA", "0" if impl == "flat" else "1")
     rng = np.random.default_rng(4242 + span_db)
@@ -391,24 +397,36 @@ def test_direct_high_dynamic_range_comb(cuda_device, gsdr_lib, oracle_mod, monke
     dem = make_direct(freq, rate, M, F, L)
     assert dem.kernel_name.startswith("ddc_mfma") == (impl == "mfma")
     ref = oracle_mod.Direct(freq, rate, M, F, L)
-    worst_strong = worst_weak = worst_all = 0.0
+    from oracle import recipe_b
+    ref32 = recipe_b.Direct(freq, rate, M, F, L, acc=np.complex64)     # the reference's fp32 order
+    worst_strong = worst_weak = worst_all = worst_weak32 = worst_ratio = 0.0
     for c in range(3):
         x = make(c, 50 + c)
         y = run_device(dem, x, cuda_device).reshape(-1, N)
         yr = ref.process(x)
-        assert y.shape == yr.shape
+        y32 = ref32.process(x)
+        assert y.shape == yr.shape == y32.shape
+        den = np.linalg.norm(yr[F:].astype(np.complex128), axis=0)
         d = y[F:].astype(np.complex128) - yr[F:]
-        err = np.linalg.norm(d, axis=0) / np.linalg.norm(yr[F:].astype(np.complex128), axis=0)
+        err = np.linalg.norm(d, axis=0) / den
+        err32 = np.linalg.norm(y32[F:].astype(np.complex128) - yr[F:], axis=0) / den
+        bound = np.maximum(TOL, 3.0 * err32)
+        k = int(np.argmax(err / bound))
+        assert (err <= bound).all(), (impl, span_db, c, k, float(err[k]), float(err32[k]), err[-4:].tolist(), err32[-4:].tolist())
+        assert err.max() <= 1.5e-5, (impl, span_db, c, float(err.max()))
         worst_strong = max(worst_strong, float(err[: N // 2].max()))
         worst_weak = max(worst_weak, float(err[N // 2:].max()))
+        worst_weak32 = max(worst_weak32, float(err32[N // 2:].max()))
+        worst_ratio = max(worst_ratio, float((err / np.maximum(err32, 1e-12)).max()))
         worst_all = max(worst_all, float(np.linalg.norm(d) / np.linalg.norm(yr[F:].astype(np.complex128))))
     dem.close()
     record_margin(worst_strong, "strong half of the comb")
     record_margin(worst_weak, f"weak half of the comb (down to -{span_db} dB)")
+    record_margin(worst_weak32, f"weak half of the comb, the reference's fp32 order on the CPU (oracle/recipe_b.py, complex64)")
+    record_margin(worst_ratio, "largest per-tone ratio HIP error / fp32-restatement error (both against the fp64 oracle)")
     record_margin(worst_all, "all tones together (error against the comb's total power)")
     assert worst_strong <= TOL, worst_strong
     assert worst_all <= 1e-6, worst_all
-    assert worst_weak <= (TOL if span_db <= 40 else 3e-5), (impl, span_db, worst_weak)
 
 
 @pytest.mark.parametrize("path", ["fft", "ddc"])
@@ -436,21 +454,29 @@ def test_tones_high_dynamic_range_comb(cuda_device, gsdr_lib, oracle_mod, monkey
         (path == "fft" or dem.kernel_name.startswith("ddc_mfma"))
     ref = oracle_mod.Pfb(freq, rate, nfft, F, L)
     np.testing.assert_array_equal(dem.bins(), ref.bins())
-    worst_strong = worst_weak = worst_all = 0.0
+    from oracle import recipe_b
+    ref32 = recipe_b.Pfb(freq, rate, nfft, F, L)       # the reference's mechanics in complex64 (numpy.fft for cuFFT)
+    worst_strong = worst_weak = worst_all = worst_weak32 = 0.0
     for c in range(3):
         x = host_tones(L, c * L, rate, freq, ampl, phase, sigma=1e-5, seed=900 + c)
         y = run_device(dem, x, cuda_device)
         yr = ref.process(x)
-        assert y.size == yr.size and yr.size
+        y32 = np.asarray(ref32.process(x))
+        assert y.size == yr.size == y32.size and yr.size
         y, yr = y.reshape(-1, N).astype(np.complex128), yr.reshape(-1, N).astype(np.complex128)
         d = y - yr
-        err = np.linalg.norm(d, axis=0) / np.linalg.norm(yr, axis=0)
+        den = np.linalg.norm(yr, axis=0)
+        err = np.linalg.norm(d, axis=0) / den
+        err32 = np.linalg.norm(y32.reshape(-1, N).astype(np.complex128) - yr, axis=0) / den
+        assert (err <= np.maximum(TOL, 3.0 * err32)).all(), (path, span_db, c, float(err.max()), float(err32.max()))
         worst_strong = max(worst_strong, float(err[: N // 2].max()))
         worst_weak = max(worst_weak, float(err[N // 2:].max()))
+        worst_weak32 = max(worst_weak32, float(err32[N // 2:].max()))
         worst_all = max(worst_all, float(np.linalg.norm(d) / np.linalg.norm(yr)))
     dem.close()
     record_margin(worst_strong, "strong half of the comb")
     record_margin(worst_weak, f"weak half of the comb (down to -{span_db} dB)")
+    record_margin(worst_weak32, "weak half of the comb, the reference's mechanics in complex64 on the CPU (oracle/recipe_b.py)")
     record_margin(worst_all, "all tones together (error against the comb's total power)")
     assert worst_strong <= TOL, worst_strong
     assert worst_all <= 1e-6, worst_all
@@ -1117,6 +1143,57 @@ def test_mixed_entries_and_streams_keep_the_stream_state_in_order(cuda_device, g
     b.close()
 
 
+def test_caller_streams_may_be_destroyed_between_calls(cuda_device, gsdr_lib):
+    """Every call arrives on a stream of its own, created for it and destroyed by the caller as soon as
+    include/gsdr.h allows: once the NEXT call on the handle has been made -- while work on it may still be
+    executing (a busy stream in front).  The handle must not touch a stream after that (it forgets a stream
+    when the next call has joined it) and must not lose the order of the carry: bit-equal to the same buffers
+    through one stream.  (Destroying a stream BEFORE the next call is outside the contract and cannot be made
+    safe: HIP itself faults when an event is recorded on a destroyed stream -- tried, a segmentation fault inside
+    hipEventRecord -- and an event of the handle's own behind every call costs 3 - 4 us of stream time per call.)"""
+    import ctypes as C
+    import torch
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipStreamCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+    hip.hipStreamDestroy.argtypes = [C.c_void_p]
+    rng = np.random.default_rng(31337)
+    N, rate, M, F, L = 64, 10_000_000, 100, 4, 100_000
+    freq = rng.choice(np.arange(-rate // 2 + 1, rate // 2), size=N, replace=False)
+    a, b = make_direct(freq, rate, M, F, L), make_direct(freq, rate, M, F, L)
+    nbuf = 8
+    xs = [torch.from_numpy(crandn(rng, L) * np.float32(10.0 ** rng.uniform(-2, 2))).to(cuda_device) for _ in range(nbuf)]
+    want = []
+    for x in xs:
+        out = torch.empty(a.out_capacity, dtype=torch.complex64, device=cuda_device)
+        n = a.process_device(x, out)
+        torch.cuda.synchronize()
+        want.append(out[:n].cpu().numpy())
+    ballast = torch.randn(4096, 4096, device=cuda_device)
+    outs = [torch.empty(b.out_capacity, dtype=torch.complex64, device=cuda_device) for _ in range(nbuf)]
+    lens = []
+    torch.cuda.synchronize()
+    prev = None
+    for k in range(nbuf):
+        raw = C.c_void_p()
+        assert hip.hipStreamCreateWithFlags(C.byref(raw), 1) == 0          # hipStreamNonBlocking
+        st = torch.cuda.ExternalStream(raw.value, device=cuda_device)
+        with torch.cuda.stream(st):
+            for _ in range(3):
+                ballast = ballast @ ballast * 1e-4                          # the call's work starts late
+        lens.append(b.process_device(xs[k], outs[k], st))
+        del st
+        if prev is not None:
+            assert hip.hipStreamDestroy(prev) == 0                          # the next call has been made: allowed
+        prev = raw
+    torch.cuda.synchronize()
+    for k in range(nbuf):
+        assert lens[k] == want[k].size
+        np.testing.assert_array_equal(outs[k][:lens[k]].cpu().numpy(), want[k], err_msg=f"buffer {k}")
+    assert hip.hipStreamDestroy(prev) == 0         # nothing follows on this handle but close()
+    a.close()
+    b.close()
+
+
 @pytest.mark.parametrize("asm", ["2", "4"], ids=["ring", "ring16"])
 @pytest.mark.parametrize("overlap,streams", [("1", "2"), ("1", "3"), ("0", "2")])
 def test_pipelined_submit_device_overlapping_buffers(cuda_device, gsdr_lib, oracle_mod, monkeypatch, overlap,
@@ -1546,7 +1623,10 @@ def test_two_front_ends_on_one_gpu_do_not_disturb_each_other(cuda_device, gsdr_l
     board share the GPU).  A heavy matrix-core DIRECT handle streams on one thread while TONES (in-LDS FFT),
     the undecimated mix, the chirp lock-in, a second DIRECT handle and the TX tone comb generator run on threads and
     streams of their own; every result of the
-    small handles must be bit-identical to what the same handle produces on an idle GPU.
+    small handles must be bit-identical to what the same handle produces on an idle GPU.  Round 3 adds the
+    TX chirp generator and the synthetic IQ source (source_chirp_kernel, source_tones_kernel): they run beside
+    another handle's loop in the TX + RX use (ref: cpp/USRP_server_link_threads.cpp:121,136) and are built
+    without packed FP32 since.
 
     What this guards: rule R3 of DESIGN.md section 4.1 holds ACROSS kernels -- a kernel in which the compiler
     used v_pk_*_f32 returns wrong values now and then while a wave of the matrix-core loop shares its SIMD
@@ -1593,7 +1673,35 @@ def test_two_front_ends_on_one_gpu_do_not_disturb_each_other(cuda_device, gsdr_l
         def close(self):
             self.gen.close()
 
-    cases = {"chirp": mk_chirp, "tones": mk_tones, "mix": mk_mix, "direct": mk_direct, "tx": TxAsDem}
+    class TxChirpAsDem(TxAsDem):
+        """the TX chirp generator (source_chirp_kernel) the same way"""
+        def __init__(self):
+            self.gen = g.TX_buffer_generator(g.param(mode="TX", rate=rate, buffer_len=L, freq=[-rate // 2], chirp_f=[rate // 2],
+                                                     swipe_s=[1_000_000], chirp_t=[1.0], ampl=[0.5], wave_type=[g.w_type.CHIRP]))
+            self.out_capacity = L
+
+    class SourceAsDem:
+        """the synthetic in-memory IQ source (source_tones_kernel): what stands in for the receiver beside the
+        demodulators of the other front-end"""
+        out_capacity = L
+
+        def __init__(self):
+            from gpu_sdr_amd.source import tone_comb
+            self.comb = tone_comb(12, rate, seed=3)
+            self.k = 0
+
+        def process_device(self, x, out, stream=None):
+            from gpu_sdr_amd.source import device_tones
+            f, a, ph = self.comb
+            device_tones(out, self.k * L, rate, f, a, ph, sigma=1e-3, seed=self.k, stream=stream)
+            self.k += 1
+            return L
+
+        def close(self):
+            pass
+
+    cases = {"chirp": mk_chirp, "tones": mk_tones, "mix": mk_mix, "direct": mk_direct, "tx": TxAsDem,
+             "tx_chirp": TxChirpAsDem, "source": SourceAsDem}
     xs = [torch.from_numpy(crandn(rng, L)).to(cuda_device) for _ in range(4)]
     refs = {}
     for name, mk in cases.items():

@@ -140,6 +140,30 @@ def test_chirp_derive_matches_oracle(gsdr_lib, oracle_mod):
         assert (a.num_steps, a.length, a.chirpness, a.f0) == (b.num_steps, b.length, b.chirpness, b.f0), c
 
 
+def test_chirp_derive_tx_matches_oracle_and_recipe_b(gsdr_lib, oracle_mod):
+    """The TX generator's own derivation (ref: cpp/USRP_buffer_generator.cpp:107-129): three statements of it
+    agree -- the library, the C oracle, the numpy restatement -- including the corner the RX derivation does
+    not have: swipe_s > chirp_t * rate resets num_steps BEFORE the slope is computed (:118-125)."""
+    import gpu_sdr_amd as g
+    from gpu_sdr_amd.demodulator import chirp_derive_tx
+    from oracle import recipe_b
+    cases = [(200_000_000, -100_000_000, 100_000_000, 1_000_000, 1.0),
+             (200_000_000, -80_000_000, 80_000_000, 10_000, 2e-5),      # 4000 samples for 10000 steps: reset
+             (1_000_000, -100_000, 100_000, 5000, 0.001),               # reset
+             (1_000_000, -100_000, 100_000, 0, 0.001),                  # swipe_s < 1
+             (100_000_000, 10_000_000, -40_000_000, 5000, 0.01),
+             (200_000_000, 200_000_000, 100_000_000, 100, 1e-9)]
+    differ = 0
+    for c in cases:
+        a, b, r = chirp_derive_tx(*c), oracle_mod.chirp_params_tx(*c), recipe_b.chirp_params_tx(*c)
+        assert (a.num_steps, a.length, a.chirpness, a.f0) == (b.num_steps, b.length, b.chirpness, b.f0), c
+        if b.f0 != -2**31:       # (recipe_b states f0 for in-range values only)
+            assert (b.num_steps, b.length, b.chirpness, b.f0) == r, c
+        rx = g.chirp_derive(*c)
+        differ += (rx.num_steps, rx.chirpness) != (a.num_steps, a.chirpness)
+    assert differ >= 2     # the reset cases really are different from the RX derivation
+
+
 def _param_c(**kw):
     from gpu_sdr_amd import _lib
     keep = []
@@ -287,8 +311,9 @@ def test_assembly_kernels_keep_two_waves_per_simd(gsdr_lib, tmp_path):
         # and packed FP32 only where it is meant to be: a wave executing v_pk_*_f32 returns stale values now
         # and then while a wave of the matrix-core loop shares its SIMD (rule 3 --
         # across kernels of concurrently used handles too), so every kernel that can meet that loop is built
-        # with no-packed-fp32-ops.  Exempt: the packed-FP32 DDC itself (engine of GSDR_DDC_MFMA=0), the
-        # compiler-scheduled matrix-core kernel (A/B runs only) and the synthetic sources of bench.py
+        # with no-packed-fp32-ops -- since round 3 the synthetic sources / TX chirp generator too (TX and RX share
+        # the GPU).  Exempt: the packed-FP32 DDC itself (engine of GSDR_DDC_MFMA=0, where no matrix-core loop
+        # runs) and the compiler-scheduled matrix-core kernel (A/B runs only)
         sym, packed = "?", {}
         for ln in dis.splitlines():
             m = re.match(r"^[0-9a-f]+ <(\S+)>:", ln)
@@ -296,7 +321,7 @@ def test_assembly_kernels_keep_two_waves_per_simd(gsdr_lib, tmp_path):
                 sym = m.group(1)
             elif re.search(r"\bv_pk_[a-z]+_f32\b", ln):
                 packed[sym] = packed.get(sym, 0) + 1
-        allowed = ("ddc_flat_kernel", "ddc_mfma_kernelILi", "source_tones_kernel", "source_chirp_kernel")
+        allowed = ("ddc_flat_kernel", "ddc_mfma_kernelILi")
         offenders = {k: v for k, v in packed.items() if not any(a in k for a in allowed)}
         assert not offenders, (f.name, offenders)
 

@@ -173,6 +173,11 @@ def test_bench_main_two_ranks_stub_engine():
     want = 2 * 20 * R * 1_000_000 / (ms * 1e-3 * 20 * R) / 1e6
     assert abs(line["value"] - want) / want < 1e-3
     assert line["roofline"] is not None and line["roofline"]["kernel"] == "stub_kernel"
+    # every rank's own clock is in the line: the fast rank (1 ms per step) is visibly twice as fast as the slow one
+    pr = line["per_rank"]
+    assert [p["rank"] for p in pr] == [0, 1]
+    assert 0.9 <= pr[0]["ms_per_step"] <= 1.9 and 1.9 <= pr[1]["ms_per_step"] <= 4.0, pr
+    assert pr[1]["ms_per_step"] <= ms * 1.001
 
 
 def test_bench_refuses_timing_switches():

@@ -28,6 +28,8 @@ R2_MIN_MFMAS = 5
 def parse(path):
     text = open(path).read()
     m = re.search(r"#define \w+_TEXT \\\n(.*?)\n    \"\"", text, re.S)
+    if not m:
+        return None          # not a generated MFMA loop (ddc_steps_gen.h has no _TEXT block)
     body = m.group(1)
     lines = re.findall(r'"(.*?)\\n\\t"', body)
     return lines
@@ -67,6 +69,8 @@ def loops(lines):
 
 def check(path):
     lines = parse(path)
+    if lines is None:
+        return None
     errs = []
     found = loops(lines)
     if not found:
@@ -136,12 +140,20 @@ def check(path):
 
 
 def main():
-    bad = []
+    bad, checked = [], 0
     for p in sys.argv[1:]:
-        bad += check(p)
+        r = check(p)
+        if r is None:
+            print(f"{p}: skipped (no *_TEXT assembly block: not a generated MFMA loop)")
+            continue
+        checked += 1
+        bad += r
     for b in bad:
         print(b)
-    print(f"{len(sys.argv) - 1} file(s), {len(bad)} violation(s)")
+    print(f"{checked} file(s) checked, {len(bad)} violation(s)")
+    if checked == 0:
+        print("nothing was checked: pass the generated headers, e.g. gpu_sdr_amd/csrc/ddc_mfma_ring*_gen.h")
+        sys.exit(2)
     sys.exit(1 if bad else 0)
 
 

@@ -382,8 +382,9 @@ def role_code(out, role):
     out.extend(advance_load_pointers("C"))
     o("s_nop 4")
     gload_ops(cnt, out, "C", *T1)
-    o("s_waitcnt vmcnt(0)")                  # the phasor images as well
+    o("s_waitcnt vmcnt(0)")                  # the phasor images and the segment maxima as well
     cnt.vm = []
+    out.extend(scale_compute())
     out.extend(produce_ops(None, None, None))
     o(f"v_add_u32 {vr(ADDR['B'][0])}, {role * SLOT}, %[wr16]")
     o(f"ds_write_b128 {vr(ADDR['B'][0])}, {vr(HI4, 4)}")
@@ -447,6 +448,46 @@ def role_code(out, role):
     o(f"{L3}:")
 
 
+# ---- the scale of the lane's output row, inside the prologue -------------------------------------
+# S = 2^se with se = 140 - (biased exponent of the largest finite |x| of the row's window), clamped to
+# +-100 (row_scale_exp in csrc/ddc_mfma.hip, bit for bit).  The window's segment maxima -- up to eight
+# entries of the table absmax_kernel left, seg[q0 .. q0 + span] -- are loaded HERE, with the phasor
+# images and the first input blocks, and reduced behind the prologue's one s_waitcnt vmcnt(0): computed in
+# C++ in front of this block they cost every workgroup a memory round trip of their own (2 us of a 20 us
+# workgroup on C2).  %[sgo]: byte offset of seg[q0]; %[sgn]: span; s[S_SC:S_SC+1]: the table.
+SG_T = CA[1]               # 8 offsets + 8 maxima: C set A (im) is not written before the first MFMA
+
+
+def scale_loads():
+    ops = []
+    for i in range(8):
+        if i == 0:
+            ops.append(f"v_mov_b32 {vr(SG_T)}, %[sgo]")
+        else:
+            ops.append(f"v_min_u32 {vr(SG_T + i)}, {i}, %[sgn]")
+            ops.append(f"v_lshl_add_u32 {vr(SG_T + i)}, {vr(SG_T + i)}, 2, %[sgo]")
+    ops.append("s_nop 2")
+    for i in range(8):
+        ops.append(f"global_load_dword {vr(SG_T + 8 + i)}, {vr(SG_T + i)}, s[{S_SC}:{S_SC + 1}]")
+    return ops
+
+
+def scale_compute():
+    m = SG_T + 8
+    return [
+        f"v_max3_u32 {vr(m)}, {vr(m)}, {vr(m + 1)}, {vr(m + 2)}",
+        f"v_max3_u32 {vr(m + 3)}, {vr(m + 3)}, {vr(m + 4)}, {vr(m + 5)}",
+        f"v_max3_u32 {vr(m)}, {vr(m)}, {vr(m + 6)}, {vr(m + 7)}",
+        f"v_max_u32 {vr(m)}, {vr(m)}, {vr(m + 3)}",
+        f"v_bfe_u32 {vr(m)}, {vr(m)}, 23, 8",
+        f"v_sub_u32 {vr(m)}, 140, {vr(m)}",
+        f"v_max_i32 {vr(m)}, 0xffffff9c, {vr(m)}",        # -100
+        f"v_min_i32 {vr(m)}, 100, {vr(m)}",
+        f"v_add_u32 {vr(m)}, 127, {vr(m)}",
+        f"v_lshlrev_b32 {vr(V_SC)}, 23, {vr(m)}",
+    ]
+
+
 def generate():
     out = []
     o = out.append
@@ -462,7 +503,10 @@ def generate():
     o(f"s_mov_b32 s{S_PSTRIDE}, %[pstride]")
     o(f"s_mov_b32 s{S_NLEFT}, %[nhi]")
     o(f"s_add_u32 s{S_NHI1}, %[nhi], -1")
-    o(f"v_mov_b32 {vr(V_SC)}, %[scale]")
+    o(f"s_mov_b32 s{S_SC}, %[sg_lo]")
+    o(f"s_mov_b32 s{S_SC + 1}, %[sg_hi]")
+    o("s_nop 2")
+    out.extend(scale_loads())
     o(f"s_mov_b32 s{S_RD}, 0")
     o(f"s_mov_b32 s{S_RDN}, {SLOT}")
     o(f"s_mov_b32 s{S_WR}, {2 * SLOT}")
@@ -497,6 +541,9 @@ def generate():
     for q in range(8):
         base = (ACC[0] if q < 4 else ACC[1]) + 4 * (q & 3)
         o(f"ds_write_b128 %[accaddr], {vr(base, 4)} offset:{q * 1024}")
+    # ... and the lane's scale (the bits of S = 2^se): the epilogue needs 1 / S of every row again, and loading the
+    # segment maxima a second time cost it a microsecond (C2, same-box A/B)
+    o(f"ds_write_b32 %[seaddr], {vr(V_SC)}")
     o("s_waitcnt lgkmcnt(0)")
     return out
 

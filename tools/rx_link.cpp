@@ -30,6 +30,7 @@
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -111,18 +112,24 @@ static int tx_mode(int argc, char **argv) {
     if (!fout || p.buffer_len == 0) { std::fprintf(stderr, "cannot open the output file\n"); return 2; }
     RX_buffer_demodulator::device_index() = 0;
     TX_buffer_generator *generator = new TX_buffer_generator(&p);
-    float2 *buf = nullptr;
-    if (hipHostMalloc((void **)&buf, p.buffer_len * sizeof(float2)) != hipSuccess) return 1;
+    // the reference's loop (ref: cpp/USRP_server_link_threads.cpp:568-584): memory for a packet only when the
+    // parameters need it (`dynamic`: everything but TONES); for TONES tx_vector goes in UNINITIALISED -- a poisoned
+    // pointer here, so that a generator that wrote through it would fault -- and get() replaces it
+    const bool dynamic = p.dynamic_buffer();
+    float2 *pool = nullptr;
+    if (dynamic && hipHostMalloc((void **)&pool, p.buffer_len * sizeof(float2)) != hipSuccess) return 1;
     const auto t0 = std::chrono::steady_clock::now();
     for (long long k = 0; k < n_buffers; ++k) {
-        generator->get(&buf);
-        std::fwrite(buf, sizeof(float2), p.buffer_len, fout);
+        float2 *tx_vector = reinterpret_cast<float2 *>((uintptr_t)0x10);
+        if (dynamic) tx_vector = pool;                 // memory->get()
+        generator->get(&tx_vector);
+        std::fwrite(tx_vector, sizeof(float2), p.buffer_len, fout);
     }
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     generator->close();
     delete generator;
     std::fclose(fout);
-    (void)hipHostFree(buf);
+    if (pool) (void)hipHostFree(pool);
     std::printf("{\"harness\": \"tx_single_link\", \"buffers\": %lld, \"buffer_len\": %d, \"msamples_per_s_incl_file\": %.1f}\n",
                 n_buffers, (int)p.buffer_len, (double)n_buffers * (double)p.buffer_len / sec / 1e6);
     return 0;
