@@ -540,7 +540,7 @@ def rooflines(wl, r, key, period_s=None):
                     executed_mfma_tflops=round(mtfl, 1),
                     executed_mfma_frac=round(mtfl / F16_MFMA_PEAK_TFLOPS, 4),
                     frac_of_fp32_vector_peak=round(tfl / FP32_PEAK_TFLOPS, 4), **common)
-    elif r["kernel"] == "pfb_lds_kernel":
+    elif r["kernel"] in ("pfb_lds_kernel", "pfb_cu_kernel"):
         # TONES as the reference does it: polyphase filter + FFT + bin selection, a frame per workgroup
         # inside the LDS.  A few flops per byte (4 f + 5 log2 nfft per sample): HBM-bound -- one read of
         # the window, one write of the selected bins.

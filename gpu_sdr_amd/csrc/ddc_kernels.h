@@ -180,10 +180,17 @@ constexpr int kPfbLdsMaxBytes = (2 * kPfbLdsMaxN + kPfbLdsMaxPrime + 1) * 8;   /
 int pfb_lds_plan(int n, int *radices16);                 // number of stages, -1 when the length does not fit
 // logical window [carry (new_0 samples) | in (window_len - new_0)]; frames_n complete frames -> out[frame][n_out]
 // (sel: bin per output column, nullptr = all nfft bins); W[spare_begin .. +spare_n) -> carry_out
+// (round 3) a run of consecutive frames per compute unit when it fits the LDS, else a frame per workgroup; `blue`:
+// transform through Bluestein's identity at length blue->m (frame lengths with a prime factor above kPfbLdsMaxPrime;
+// tw is then the table of length m, blue->d_tw)
 hipError_t launch_pfb_lds(const float2 *carry, int new_0, const float2 *in, const float *window, const float2 *tw,
                           int nfft, int avg, int frames_n, const int *sel, int n_out, float2 *out,
-                          float2 *carry_out, int spare_begin, int spare_n, long long window_len, hipStream_t st);
+                          float2 *carry_out, int spare_begin, int spare_n, long long window_len, hipStream_t st,
+                          const FftPlan *blue = nullptr);
 const char *pfb_lds_kernel_name();
+const char *pfb_cu_kernel_name();
+bool pfb_cu_fits(int nfft, int avg, int len);                      // does one frame fit the run kernel's LDS layout
+bool pfb_cu_takes(int nfft, int avg, int len, bool bluestein);     // ... and is it the kernel launch_pfb_lds() runs
 
 // ---- chirp ---------------------------------------------------------------
 struct ChirpShape {

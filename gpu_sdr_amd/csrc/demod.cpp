@@ -165,6 +165,7 @@ struct gsdr_demod {
     std::vector<float> pc_chirp_t;
     // ---- TONES / NOISE, a frame per workgroup: filter + in-LDS transform + bin selection (fft_kernels.hip) ----
     bool pfb_lds = false;
+    bool pfb_blue = false;                           // ... through Bluestein's identity (h->fft holds chirp, transform, twiddles)
     float2 *d_pfb_tw = nullptr;                      // w_nfft^k
     int *d_pfb_sel = nullptr;                        // TONES: bin of every output column
     float2 *d_pfb_carry[kStageSets] = {};            // the samples a call leaves over (at most F*nfft)
@@ -870,22 +871,24 @@ int enqueue_pfb_lds(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t st
     }
     const int *sel = h->mode == GSDR_NOISE ? nullptr : h->d_pfb_sel;
     const long long wlen = (long long)h->bh.new_0 + h->L;
+    const gsdr::FftPlan *blue = h->pfb_blue ? &h->fft : nullptr;
+    const float2 *tw = h->pfb_blue ? h->fft.d_tw : h->d_pfb_tw;
     hipEvent_t stop = nullptr;
     if (h->pipe_overlap) {
         // overlapped entry: consecutive buffers run on the compute streams in turn.  What ties them
         // together is the carry alone: a launch of its own copies this call's leftovers first (it needs
         // the previous call's carry and this buffer, nothing of this call's frames), its event lets the
         // next call start, and the frames follow -- beside the frames of the neighbouring buffers.
-        HIPCHK(h, gsdr::launch_pfb_lds(carry, h->bh.new_0, in, h->d_fft_win, h->d_pfb_tw, h->nfft, h->F, 0,
-                                       sel, h->ddc_channels, out, carry_out, h->bh.spare_begin, spare_n, wlen, st));
+        HIPCHK(h, gsdr::launch_pfb_lds(carry, h->bh.new_0, in, h->d_fft_win, tw, h->nfft, h->F, 0,
+                                       sel, h->ddc_channels, out, carry_out, h->bh.spare_begin, spare_n, wlen, st, blue));
         HIPCHK(h, hipEventRecord(h->ev_abs[h->pipe_seq % 4], st));
         if (record_begin(h, st, &stop)) return -1;
-        HIPCHK(h, gsdr::launch_pfb_lds(carry, h->bh.new_0, in, h->d_fft_win, h->d_pfb_tw, h->nfft, h->F, cb,
-                                       sel, h->ddc_channels, out, nullptr, 0, 0, wlen, st));
+        HIPCHK(h, gsdr::launch_pfb_lds(carry, h->bh.new_0, in, h->d_fft_win, tw, h->nfft, h->F, cb,
+                                       sel, h->ddc_channels, out, nullptr, 0, 0, wlen, st, blue));
     } else {
         if (record_begin(h, st, &stop)) return -1;
-        HIPCHK(h, gsdr::launch_pfb_lds(carry, h->bh.new_0, in, h->d_fft_win, h->d_pfb_tw, h->nfft, h->F, cb,
-                                       sel, h->ddc_channels, out, carry_out, h->bh.spare_begin, spare_n, wlen, st));
+        HIPCHK(h, gsdr::launch_pfb_lds(carry, h->bh.new_0, in, h->d_fft_win, tw, h->nfft, h->F, cb,
+                                       sel, h->ddc_channels, out, carry_out, h->bh.spare_begin, spare_n, wlen, st, blue));
     }
     if (stop) HIPCHK(h, hipEventRecord(stop, st));
     h->win_seq++;
@@ -1173,13 +1176,22 @@ gsdr_demod *gsdr_demod_create(const gsdr_param_c *p) {
             // GSDR_PFB_LDS=0, GSDR_TONES_FFT=0 (TONES only) or such a length leave TONES to the DDC
             // kernels (every selected bin as a tone) and NOISE to the global-memory FFT stages.
             int radices16[16];
-            const bool lds_path = env_int("GSDR_PFB_LDS", 1) != 0 && gsdr::pfb_lds_plan(h->nfft, radices16) >= 0 &&
+            const bool direct_ok = gsdr::pfb_lds_plan(h->nfft, radices16) >= 0;
+            // a prime factor above 127 (or GSDR_PFB_BLUESTEIN=1: any length, for tests): Bluestein's identity inside
+            // the workgroup, when a frame at the padded length m = 2^ceil(log2(2 nfft - 1)) fits the LDS
+            long long blue_m = 1;
+            while (blue_m < 2LL * h->nfft - 1) blue_m <<= 1;
+            const bool blue_ok = (!direct_ok || env_int("GSDR_PFB_BLUESTEIN", 0) != 0) && env_int("GSDR_PFB_BLUESTEIN", 1) != 0 &&
+                                 blue_m <= gsdr::kPfbLdsMaxN && gsdr::pfb_cu_fits(h->nfft, F, (int)blue_m);
+            const bool lds_path = env_int("GSDR_PFB_LDS", 1) != 0 && (direct_ok || blue_ok) &&
                                   (noise ? noise_fft : env_int("GSDR_TONES_FFT", 1) != 0);
             if (lds_path) {
                 h->pfb_lds = true;
+                h->pfb_blue = blue_ok;
                 h->F = F;
                 h->M = h->nfft;
-                h->kernel_name = gsdr::pfb_lds_kernel_name();
+                h->kernel_name = gsdr::pfb_cu_takes(h->nfft, F, blue_ok ? (int)blue_m : h->nfft, blue_ok) ? gsdr::pfb_cu_kernel_name()
+                                                                                                          : gsdr::pfb_lds_kernel_name();
                 std::vector<float2> tw((size_t)h->nfft);
                 for (int k = 0; k < h->nfft; ++k) {
                     const double a = -2.0 * M_PI * (double)k / (double)h->nfft;
@@ -1188,6 +1200,8 @@ gsdr_demod *gsdr_demod_create(const gsdr_param_c *p) {
                 std::vector<int> sel(tone.begin(), tone.end());
                 bool ok = upload(&h->d_pfb_tw, tw) == hipSuccess && upload(&h->d_fft_win, h->window) == hipSuccess &&
                           (noise || upload(&h->d_pfb_sel, sel) == hipSuccess);
+                // Bluestein: the chirp, its transform and the twiddles of length m (fft_plan_build makes exactly these)
+                if (ok && blue_ok) ok = gsdr::fft_plan_build(h->fft, h->nfft) == 0 && h->fft.m == (int)blue_m;
                 const size_t ncarry = (size_t)h->nfft * F + 8;
                 for (int i = 0; i < kStageSets && ok; ++i)
                     ok = dev_alloc(&h->d_pfb_carry[i], ncarry) == hipSuccess &&
@@ -1200,7 +1214,7 @@ gsdr_demod *gsdr_demod_create(const gsdr_param_c *p) {
             // memory (§4.5) -- NOISE keeps every bin, TONES picks its bins out of a scratch spectrum.  For
             // TONES this replaces one DDC per bin when the frame is long (above 8192 points a frame is a
             // window of 32 768+ samples: the DDC rows become thousand-block loops on a handful of workgroups)
-            const bool tones_global = !noise && env_int("GSDR_TONES_FFT", 1) != 0 && h->nfft > gsdr::kPfbLdsMaxN;
+            const bool tones_global = !noise && env_int("GSDR_TONES_FFT", 1) != 0;
             if (noise_fft || tones_global) {
                 h->noise_fft = true;
                 h->F = F;
@@ -1740,7 +1754,8 @@ int gsdr_demod_describe(const gsdr_demod *h, char *buf, int cap) {
     s += "\", \"kernel\": \"";
     s += h->kernel_name;
     s += "\", \"family\": \"";
-    s += h->pfb_lds ? "polyphase filter + fp32 Stockham FFT inside the LDS + bin selection, one launch" :
+    s += h->pfb_lds ? (h->pfb_blue ? "polyphase filter + Bluestein (two fp32 Stockham FFTs) inside the LDS + bin selection, one launch"
+                                   : "polyphase filter + fp32 Stockham FFT inside the LDS + bin selection, one launch") :
          h->noise_fft ? "fp32 Stockham FFT behind the polyphase filter" : h->mfma ? "f16 MFMA, hi/lo split" : (h->mode == GSDR_CHIRP ? "fp32 VALU, integer phase" : (h->pipe ? "packed fp32 VALU" : "fp32 VALU"));
     s += "\", \"channels\": " + std::to_string(h->ddc_channels > 0 ? h->ddc_channels : h->N);
     s += ", \"row_tiles_per_workgroup\": " + std::to_string(h->mfma ? h->last_rt : 0);

@@ -20,6 +20,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <vector>
 
 #include "ddc_kernels.h"
@@ -468,6 +469,505 @@ __global__ __launch_bounds__(NT) GSDR_NO_PK void pfb_lds_kernel(const PfbLdsArgs
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// Round 3: a RUN of consecutive frames per workgroup, one workgroup (1024 threads) per compute unit.
+//
+// pfb_lds_kernel above gives every frame a workgroup of its own; all workgroups of a launch start together
+// and stay in step: six microseconds in which every compute unit waits for its filter loads, then five in
+// which the memory system idles while they all transform (profiles/r02_stamp_pfb.log: 785 GB/s = 0.098 of the
+// HBM peak).  Frame r and frame r+1 share F-1 of their F blocks, and each of those workgroups pulled all F
+// through its own 8-byte loads: 32 load instructions per thread and round trip.
+//
+// Here the grid is one workgroup per compute unit (G = frames / 256 consecutive frames each: ~3 900 samples of
+// new data per unit at any frame length), and a workgroup
+//   1. stages the raw samples of its run ONCE -- (G + F - 1) n samples, 16 bytes per lane and load, four or five
+//      loads per thread, one memory round trip -- into the LDS (the region the transform's second buffer uses
+//      later), the window taps of its points into registers on the same trip;
+//   2. filters out of the LDS (float accumulation in tap order, as the reference's kernel,
+//      ref: cpp/kernels.cu:474-516);
+//   3. transforms all G frames together: a stage is one butterfly per thread over the whole run, so the
+//      barrier-separated stages are as many as for one frame;
+//   4. selects the bins and stores.
+// A prime factor above 13 is the first stage as before, one output pair per work item now (item = frame, q,
+// column: four times the items of the four-column version, a quarter of the chain each).
+// Frame lengths with a prime factor above 127 (or any length, GSDR_PFB_BLUESTEIN=1) go through Bluestein's
+// identity INSIDE the workgroup: chirp, zero padding to m = 2^ceil(log2(2n-1)) <= 8192, two radix-4/2
+// transforms of length m around a pointwise product with the chirp's transform (host-made, double), chirp
+// again -- the reference takes any fft_tones through one cufftPlanMany (ref: cpp/USRP_demodulator.cpp:150-153).
+// ---------------------------------------------------------------------------------------------
+constexpr int kPfbCuThreads = 1024;
+constexpr int kPfbCuPts = 6;                     // filter points per thread at most: G * n <= 6 * 1024
+constexpr int kPfbCuMaxBytes = 156 * 1024;       // of the 160 KiB of a compute unit
+
+struct PfbCuArgs {
+    const float2 *carry, *in;
+    const float *window;
+    const float2 *tw;          // w_len^k, k < len
+    const int *sel;
+    float2 *out, *carry_out;
+    const float2 *chirp;       // Bluestein: exp(+i pi k^2 / n), k < n; nullptr: the frame length is transformed directly
+    const float2 *bhat;        // Bluestein: the transform (length m) of the wrapped chirp
+    int n, F, frames_n, n_out, new_0, G, len;    // len: transform length (n, or m)
+    int spare_begin, spare_n;
+    unsigned main_blocks, blocks_per_xcd;
+    int n_radices;
+    int radices[16];
+    unsigned mag_n, mag_nout, mag_len, mag_pad, mag_ht;
+    unsigned mag_t[16], mag_p[16];
+    int stage_t[16], stage_tws[16];
+    int b_off, b_len;          // second buffer: offset and length (float2), also holds the raw samples first
+    int twl;                   // the twiddle table goes into the LDS too
+};
+
+// the prime-first stage with one (q, column) pair per work item; see lds_stage_prime_first
+__device__ __forceinline__ void lds_stage_prime_first1(int R, float2 *src, float2 *dst, int n, const float2 *roots,
+                                                       int t, unsigned mag_t, unsigned mag_ht, int FR, int tid, int NT) {
+    const int h = (R - 1) >> 1;
+    for (int g = tid; g < FR * h * t; g += NT) {
+        const int rr = fdiv(g, mag_t), i = g - rr * t;          // rr = fr * h + (r - 1)
+        const int fr = FR == 1 ? 0 : rr / h, r = rr - fr * h + 1;
+        const int lo = fr * n + i + r * t, hi = fr * n + i + (R - r) * t;
+        const float2 x = src[lo], y = src[hi];
+        src[lo] = mk2(x.x + y.x, x.y + y.y);
+        src[hi] = mk2(x.x - y.x, x.y - y.y);
+    }
+    __syncthreads();
+    const int per = (h + 1) * t;
+    for (int g = tid; g < FR * per; g += NT) {
+        const int fr = FR == 1 ? 0 : fdiv(g, mag_ht), rem = g - fr * per;
+        const int q = fdiv(rem, mag_t), i = rem - q * t;
+        const float2 *xb = src + fr * n + i;
+        const float2 x0 = xb[0];
+        float ax = 0.f, ay = 0.f, bx = 0.f, by = 0.f;
+        int idx = 0;
+#pragma unroll 4
+        for (int r = 1; r <= h; ++r) {
+            idx += q;
+            idx = idx >= R ? idx - R : idx;
+            const float2 w = roots[idx];             // (cos, -sin)
+            const float2 S = xb[r * t], D = xb[(R - r) * t];
+            ax = fmaf(S.x, w.x, ax);
+            ay = fmaf(S.y, w.x, ay);
+            bx = fmaf(D.x, -w.y, bx);
+            by = fmaf(D.y, -w.y, by);
+        }
+        const int o = fr * n + i * R;
+        const float cx = x0.x + ax, cy = x0.y + ay;
+        dst[o + q] = mk2(cx + by, cy - bx);
+        if (q != 0) dst[o + R - q] = mk2(cx - by, cy + bx);
+    }
+}
+
+// The prime-first stage as two small dense real matrix products on the matrix cores (v_mfma_f32_16x16x4_f32: exact
+// f32 products, f32 accumulate -- this IS a dense contraction, unlike the rest of the path).  After the S / D pass
+// (see lds_stage_prime_first) the stage is
+//     A[q][c] = sum_(r=1..h) cos(2 pi q r / R) S_r[c],    B[q][c] = sum_(r=1..h) sin(2 pi q r / R) D_r[c],
+// q = 0 .. h, over the columns c = (frame, column i, re | im) -- 2 FR t real columns -- and
+//     out[q] = x_0 + A - iB,   out[R - q] = x_0 + A + iB.
+// On the VALU that is an instruction per multiply-add plus the LDS reads and index arithmetic around it:
+// 7.2 us of a 1230-point run of four frames (R = 41), 14.6 us of a 1016-point run (R = 127) -- more than everything
+// else of those launches together (profiles/r03_stamp_pfb_cu.log).  A wave takes 16 x 16 tiles of (q, c): per step
+// of four r one root (cos, -sin) and one S and one D value per lane out of the LDS, two MFMAs.
+typedef float pfb_f4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void lds_stage_prime_first_mfma(int R, const float2 *src, float2 *dst, int n, const float2 *roots,
+                                                           int t, unsigned mag_t, int FR, int tid, int NT) {
+    // S_r = x_r + x_(R-r) and D_r = x_r - x_(R-r) are formed where they are used (two LDS reads and two additions
+    // per operand: a pass of its own that forms them in place cost a microsecond and a barrier).  Tiles of 16 x 16
+    // (v_mfma_f32_16x16x4_f32, four r per step): R = 127 over a run of four 1016-point frames is 4 x 4 tiles --
+    // every wave of the workgroup has one -- where 32 x 32 tiles left all but two or four waves idle.
+    const int h = (R - 1) >> 1;
+    const float *sf = reinterpret_cast<const float *>(src);
+    float *df = reinterpret_cast<float *>(dst);
+    const int lane = tid & 63, wave = tid >> 6, nwaves = NT >> 6;
+    const int l16 = lane & 15, l4 = lane >> 4;
+    const int NC = 2 * FR * t;                                  // real columns: (frame, i, re | im)
+    const int MT = (h + 1 + 15) >> 4, NTL = (NC + 15) >> 4;
+    const int steps = (h + 3) >> 2;                             // four r per step; r > h meets a zero coefficient
+    // tile -> (mt, nt) without a division: MT <= 4 (R <= kPfbLdsMaxPrime = 127)
+    for (int tile = wave; tile < MT * NTL; tile += nwaves) {
+        int mt = 0, nt = tile;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (nt >= NTL) {
+                nt -= NTL;
+                ++mt;
+            }
+        // this lane's row of the coefficient matrices and its column of S / D
+        const int q = mt * 16 + l16, qc = q <= h ? q : h;
+        int c = nt * 16 + l16;
+        const bool col_ok = c < NC;
+        c = col_ok ? c : NC - 1;
+        const int part = c & 1, ci = c >> 1;
+        const int fr = FR == 1 ? 0 : fdiv(ci, mag_t), i = ci - fr * t;
+        const int col0 = 2 * (fr * n + i) + part;               // float index of x_0's component
+        int idx = qc * (1 + l4);                                // <= 4 h < 2 R
+        idx = idx >= R ? idx - R : idx;
+        int dq = 4 * qc;
+        dq = dq >= R ? dq - R : dq;
+        int r = 1 + l4;
+        pfb_f4v accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
+        // Four steps -- eight MFMAs -- make a batch, and the operands of a batch live in registers of their own
+        // (two sets, used in turn): an MFMA reads its A and B registers pass by pass while it runs (rule R1 of
+        // DESIGN.md section 4.1).  The matrix pipe takes its instructions in order: once the eight MFMAs of batch b
+        // have been ISSUED, those of batch b-1 are complete, so the loads of batch b+1 may then land in b-1's set --
+        // and their LDS latency hides under the 256 cycles batch b is running.  `pin` keeps the compiler from using a
+        // set's registers for anything else before that point.
+        struct Ops {
+            float ac[4], as[4], bs[4], bd[4];
+        };
+        auto load = [&](Ops &o) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ru = r + 4 * u;
+                const bool live = ru <= h;
+                const int rc = live ? ru : h;                   // steps past the last: a valid address, a zero coefficient
+                const float2 w = roots[idx];                    // (cos, -sin)(2 pi q r / R)
+                const float xl = sf[col0 + 2 * rc * t], xh = sf[col0 + 2 * (R - rc) * t];
+                o.ac[u] = live ? w.x : 0.f;
+                o.as[u] = live ? -w.y : 0.f;
+                o.bs[u] = xl + xh;                              // S_r
+                o.bd[u] = xl - xh;                              // D_r
+                idx += dq;
+                idx = idx >= R ? idx - R : idx;
+            }
+            r += 16;
+        };
+        auto mma = [&](const Ops &o) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                accA = __builtin_amdgcn_mfma_f32_16x16x4f32(o.ac[u], o.bs[u], accA, 0, 0, 0);
+                accB = __builtin_amdgcn_mfma_f32_16x16x4f32(o.as[u], o.bd[u], accB, 0, 0, 0);
+            }
+        };
+        auto pin = [&](const Ops &o) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                asm volatile("" ::"v"(o.ac[u]), "v"(o.as[u]), "v"(o.bs[u]), "v"(o.bd[u]));
+        };
+        Ops oa, ob;
+        load(oa);
+        for (int s = 0; s < steps; s += 8) {
+            mma(oa);
+            load(ob);
+            pin(oa);
+            mma(ob);
+            load(oa);
+            pin(ob);
+        }
+        pin(oa);
+        if (tile == 0) fft_stamp(6);
+        // The results first, then their readers: behind the compiler's own wait count VALU reads of an MFMA's
+        // result registers may see stale values (the hazard ddc_mfma_kernel guards against, csrc/ddc_mfma.hip).
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+        // register j of a lane: row 4 (lane / 16) + j of the tile, column lane % 16;
+        //     out[q] = x_0 + A - iB,   out[R - q] = x_0 + A + iB
+        // The re and im columns of a point sit in neighbouring lanes: the cross terms are one DPP swap away.
+        const float x0p = sf[col0];
+        const float sgn = part ? -1.f : 1.f;
+        const int obase = 2 * (fr * n + i * R) + part;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int qq = mt * 16 + 4 * l4 + j;
+            // (through a scalar copy: __builtin_bit_cast applied to the vector ELEMENT accB[j] reads element 0
+            //  whatever j is)
+            const float bown = accB[j];
+            const float bp = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, bown), 0xB1, 0xf, 0xf, false));
+            const float base = x0p + accA[j];
+            if (col_ok && qq <= h) {
+                df[obase + 2 * qq] = base + sgn * bp;
+                if (qq != 0) df[obase + 2 * (R - qq)] = base - sgn * bp;
+            }
+        }
+    }
+}
+
+// The same stage on 32 x 32 tiles (v_mfma_f32_32x32x2_f32) with a POINT (frame, i) per column and its real and
+// imaginary parts as two accumulations side by side: no lane exchange, an output is one 8-byte store.  Fewer, fatter
+// tiles: the better choice when the run has many columns (R = 41 over four 1230-point frames: 120 points, stage
+// 4.3 us against 7.7 us on 16 x 16 tiles, whose per-tile set-up is paid 30 times there); with few columns (R = 127:
+// 32 points) it leaves all but two waves idle and the 16 x 16 form wins (7.2 against 8.7 us).
+typedef float pfb_f16v __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void lds_stage_prime_first_mfma32(int R, const float2 *src, float2 *dst, int n, const float2 *roots,
+                                                             int t, unsigned mag_t, int FR, int tid, int NT) {
+    const int h = (R - 1) >> 1;
+    const int lane = tid & 63, wave = tid >> 6, nwaves = NT >> 6;
+    const int l32 = lane & 31, l2 = lane >> 5;
+    const int NC = FR * t;                                      // columns: the points (frame, i)
+    const int MT = (h + 1 + 31) >> 5, NTL = (NC + 31) >> 5;     // MT <= 2: R <= kPfbLdsMaxPrime = 127
+    const int steps = (h + 1) >> 1;                             // two r per step; r > h meets a zero coefficient
+    for (int tile = wave; tile < MT * NTL; tile += nwaves) {
+        const int mt = tile >= NTL ? 1 : 0, nt = tile - mt * NTL;
+        // this lane's row of the coefficient matrices (q * r < R for q <= h, r <= 2: no reduction needed at the start)
+        const int q = mt * 32 + l32, qc = q <= h ? q : h;
+        int c = nt * 32 + l32;
+        const bool col_ok = c < NC;
+        c = col_ok ? c : NC - 1;
+        const int fr = FR == 1 ? 0 : fdiv(c, mag_t), i = c - fr * t;
+        const float2 *xc = src + fr * n + i;                    // x_r of this column: xc[r * t]
+        int idx = qc * (1 + l2);
+        const int dq = 2 * qc;                                  // < R
+        int r = 1 + l2;
+        pfb_f16v aRe = {0}, aIm = {0}, bRe = {0}, bIm = {0};
+        // batches of two steps (eight MFMAs), two operand sets: see lds_stage_prime_first_mfma
+        struct Ops {
+            float ac[2], as[2], sre[2], sim[2], dre[2], dim[2];
+        };
+        auto load = [&](Ops &o) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int ru = r + 2 * u;
+                const bool live = ru <= h;
+                const int rc = live ? ru : h;                   // steps past the last: a valid address, a zero coefficient
+                const float2 w = roots[idx];                    // (cos, -sin)(2 pi q r / R)
+                const float2 xl = xc[rc * t], xh = xc[(R - rc) * t];
+                o.ac[u] = live ? w.x : 0.f;
+                o.as[u] = live ? -w.y : 0.f;
+                o.sre[u] = xl.x + xh.x;                         // S_r
+                o.sim[u] = xl.y + xh.y;
+                o.dre[u] = xl.x - xh.x;                         // D_r
+                o.dim[u] = xl.y - xh.y;
+                idx += dq;
+                idx = idx >= R ? idx - R : idx;
+            }
+            r += 4;
+        };
+        auto mma = [&](const Ops &o) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                aRe = __builtin_amdgcn_mfma_f32_32x32x2f32(o.ac[u], o.sre[u], aRe, 0, 0, 0);
+                aIm = __builtin_amdgcn_mfma_f32_32x32x2f32(o.ac[u], o.sim[u], aIm, 0, 0, 0);
+                bRe = __builtin_amdgcn_mfma_f32_32x32x2f32(o.as[u], o.dre[u], bRe, 0, 0, 0);
+                bIm = __builtin_amdgcn_mfma_f32_32x32x2f32(o.as[u], o.dim[u], bIm, 0, 0, 0);
+            }
+        };
+        auto pin = [&](const Ops &o) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                asm volatile("" ::"v"(o.ac[u]), "v"(o.as[u]), "v"(o.sre[u]), "v"(o.sim[u]), "v"(o.dre[u]), "v"(o.dim[u]));
+        };
+        Ops oa, ob;
+        load(oa);
+        for (int s = 0; s < steps; s += 4) {
+            mma(oa);
+            load(ob);
+            pin(oa);
+            mma(ob);
+            load(oa);
+            pin(ob);
+        }
+        pin(oa);
+        if (tile == 0) fft_stamp(6);
+        // the results first, then their readers (eighty cycles: the last MFMA runs 64)
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+        // register j of a lane: row 8 (j / 4) + 4 l2 + j % 4 of the tile, column l32:
+        //     out[q] = x_0 + A - iB,   out[R - q] = x_0 + A + iB
+        const float2 x0 = xc[0];
+        const int qb = mt * 32 + 4 * l2;                        // the lane's rows: qb + 8 (j / 4) + j % 4
+        float2 *oq = dst + fr * n + i * R + qb;                 // out[qb + off]
+        float2 *om = dst + fr * n + i * R + (R - qb);           // out[R - qb - off]
+        const int room = col_ok ? h - qb : -1;                  // rows with off <= room exist
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int off = 8 * (j >> 2) + (j & 3);
+            const float cx = x0.x + aRe[j], cy = x0.y + aIm[j];
+            const float bx = bRe[j], by = bIm[j];
+            if (off <= room) {
+                oq[off] = mk2(cx + by, cy - bx);
+                if (qb + off != 0) om[-off] = mk2(cx - by, cy + bx);
+            }
+        }
+    }
+}
+
+// all stages of a.radices over FR frames of `len` points; returns where the result is
+// (buffers are named by their OFFSET in the LDS array, not by pointer: a pointer that is swapped in a loop or
+//  picked by a comparison loses its address space and every ds_read behind it turns into a flat_load)
+__device__ __forceinline__ int pfb_cu_stages(const PfbCuArgs &a, float2 *lds, int src_off, int dst_off, const float2 *tw,
+                                             const float2 *roots, int st_radix, int st_mag_t, int st_mag_p,
+                                             int st_t, int st_tws, int tid) {
+    constexpr int NT = kPfbCuThreads;
+    const int len = a.len, FR = a.G;
+    int p = 1;
+    for (int s = 0; s < a.n_radices; ++s) {
+        float2 *src = lds + src_off, *dst = lds + dst_off;
+        const int R = __builtin_amdgcn_readlane(st_radix, s);
+        const unsigned mt = (unsigned)__builtin_amdgcn_readlane(st_mag_t, s), mp = (unsigned)__builtin_amdgcn_readlane(st_mag_p, s);
+        const int st = __builtin_amdgcn_readlane(st_t, s), stw = __builtin_amdgcn_readlane(st_tws, s);
+        switch (R) {
+            case 2: lds_stage<2>(src, dst, len, p, st, stw, mt, mp, tw, FR, tid, NT); break;
+            case 3: lds_stage<3>(src, dst, len, p, st, stw, mt, mp, tw, FR, tid, NT); break;
+            case 4: lds_stage<4>(src, dst, len, p, st, stw, mt, mp, tw, FR, tid, NT); break;
+            case 5: lds_stage<5>(src, dst, len, p, st, stw, mt, mp, tw, FR, tid, NT); break;
+            case 7: lds_stage<7>(src, dst, len, p, st, stw, mt, mp, tw, FR, tid, NT); break;
+            case 11: lds_stage<11>(src, dst, len, p, st, stw, mt, mp, tw, FR, tid, NT); break;
+            case 13: lds_stage<13>(src, dst, len, p, st, stw, mt, mp, tw, FR, tid, NT); break;
+            default:
+                if (s == 0 && FR * st >= 64)            // many columns: fat tiles, a point per column
+                    lds_stage_prime_first_mfma32(R, src, dst, len, roots, st, mt, FR, tid, NT);
+                else if (s == 0)
+                    lds_stage_prime_first_mfma(R, src, dst, len, roots, st, mt, FR, tid, NT);
+                else
+                    lds_stage_generic(R, src, dst, len, p, tw, FR, tid, NT);
+                break;
+        }
+        __syncthreads();
+        if (s < 2) fft_stamp(3 + s);
+        p *= R;
+        const int t2 = src_off;
+        src_off = dst_off;
+        dst_off = t2;
+    }
+    return src_off;
+}
+
+// TWL: the twiddle table is copied into the LDS (a template parameter, not a run-time choice between an LDS and a
+// global pointer: that would be a flat pointer)
+template <bool TWL>
+__global__ __launch_bounds__(kPfbCuThreads) GSDR_NO_PK void pfb_cu_kernel(const PfbCuArgs a) {
+    constexpr int NT = kPfbCuThreads;
+    extern __shared__ float2 pfb_lds[];
+    const int tid = threadIdx.x, n = a.n, len = a.len, G = a.G;
+    const unsigned padded = a.blocks_per_xcd * 8u;
+    if (blockIdx.x >= padded) {
+        // leftovers of this call -> carry of the next one (PfbLdsArgs has the same fields: one helper)
+        const int j0 = (int)(blockIdx.x - padded) * 2048;
+        for (int j = j0 + tid; j < j0 + 2048 && j < a.spare_n; j += NT) {
+            const int q = a.spare_begin + j;
+            a.carry_out[j] = q < a.new_0 ? a.carry[q] : a.in[q - a.new_0];
+        }
+        return;
+    }
+    // contiguous runs of frames per XCD (its L2 then serves the blocks neighbouring runs share)
+    const unsigned wg = (blockIdx.x & 7u) * a.blocks_per_xcd + (blockIdx.x >> 3);
+    if (wg >= a.main_blocks) return;
+    const int f0 = (int)wg * G;
+    const int Gw = a.frames_n - f0 < G ? a.frames_n - f0 : G;       // frames of this run that exist (>= 1)
+    fft_stamp(0);
+    float2 *A = pfb_lds, *B = pfb_lds + a.b_off, *roots = B + a.b_len, *twl = roots + (kPfbLdsMaxPrime + 1);
+    float2 *raw = B;
+    // the parameters of stage s live in lane s of five registers
+    const int st_lane = tid & 15;
+    const int st_radix = a.radices[st_lane], st_mag_t = (int)a.mag_t[st_lane], st_mag_p = (int)a.mag_p[st_lane];
+    const int st_t = a.stage_t[st_lane], st_tws = a.stage_tws[st_lane];
+    const int R0 = a.n_radices > 0 && a.radices[0] > 13 ? a.radices[0] : 0;
+
+    // ---- 1. loads: the window taps of this thread's points, then the raw samples of the run ----
+    int pk[kPfbCuPts], pfr[kPfbCuPts];
+    float wv[kPfbCuPts][4];
+    const int npts = G * n;
+#pragma unroll
+    for (int c = 0; c < kPfbCuPts; ++c) {
+        const int p = tid + NT * c, pc = p < npts ? p : 0;
+        pfr[c] = fdiv(pc, a.mag_n);
+        pk[c] = pc - pfr[c] * n;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wv[c][j] = a.window[(unsigned)((j < a.F ? j : a.F - 1) * n + pk[c])];
+    }
+    const int nraw = (Gw + a.F - 1) * n;
+    const int q0 = f0 * n;                                  // window position of raw[0]
+    if (q0 >= a.new_0) {
+        const float2 *src = a.in + (q0 - a.new_0);
+        typedef float f4u __attribute__((ext_vector_type(4), aligned(8)));
+        typedef float f4a __attribute__((ext_vector_type(4)));
+        for (int j = 2 * tid; j < nraw; j += 2 * NT) {
+            if (j + 1 < nraw) {
+                const f4u v = *reinterpret_cast<const f4u *>(src + j);
+                *reinterpret_cast<f4a *>(raw + j) = f4a{v.x, v.y, v.z, v.w};
+            } else {
+                raw[j] = src[j];
+            }
+        }
+    } else {
+        for (int j = tid; j < nraw; j += NT) {
+            const int q = q0 + j;
+            raw[j] = q < a.new_0 ? a.carry[q] : a.in[q - a.new_0];
+        }
+    }
+    if (TWL)
+        for (int k = tid; k < len; k += NT) twl[k] = a.tw[k];
+    for (int m = tid; m < R0; m += NT) roots[m] = a.tw[m * (len / R0)];
+    __syncthreads();
+    fft_stamp(1);
+
+    // ---- 2. polyphase filter out of the LDS (float accumulate in tap order) ----
+#pragma unroll
+    for (int c = 0; c < kPfbCuPts; ++c) {
+        const int p = tid + NT * c;
+        if (p < npts) {
+            float2 acc = mk2(0.f, 0.f);
+            if (pfr[c] < Gw) {
+                const float2 *rp = raw + pfr[c] * n + pk[c];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < a.F) {
+                        const float2 sm = rp[i * n];
+                        acc.x += sm.x * wv[c][i];
+                        acc.y += sm.y * wv[c][i];
+                    }
+                for (int i = 4; i < a.F; ++i) {
+                    const float2 sm = rp[i * n];
+                    const float w = a.window[(unsigned)(i * n + pk[c])];
+                    acc.x += sm.x * w;
+                    acc.y += sm.y * w;
+                }
+                if (a.chirp) {
+                    const float2 ch = a.chirp[pk[c]];
+                    acc = cmul(acc, mk2(ch.x, -ch.y));
+                }
+            }
+            A[pfr[c] * len + pk[c]] = acc;
+        }
+    }
+    if (len > n) {                                          // Bluestein: zero padding up to m
+        const int pad = len - n;
+        for (int g = tid; g < G * pad; g += NT) {
+            const int fr = fdiv(g, a.mag_pad);
+            A[fr * len + n + (g - fr * pad)] = mk2(0.f, 0.f);
+        }
+    }
+    __syncthreads();
+    fft_stamp(2);
+
+    // ---- 3. the transform of all G frames, stage by stage ----
+    const float2 *tw = TWL ? twl : a.tw;
+    int res_off = pfb_cu_stages(a, pfb_lds, 0, a.b_off, tw, roots, st_radix, st_mag_t, st_mag_p, st_t, st_tws, tid);
+    if (a.chirp) {
+        // d = conj(A * Bhat); the inverse transform is then a forward one (IFFT(z) = conj(FFT(conj z)) / m)
+        float2 *res = pfb_lds + res_off;
+        for (int g = tid; g < G * len; g += NT) {
+            const int fr = fdiv(g, a.mag_len);
+            const float2 v = cmul(res[g], a.bhat[g - fr * len]);
+            res[g] = mk2(v.x, -v.y);
+        }
+        __syncthreads();
+        res_off = pfb_cu_stages(a, pfb_lds, res_off, res_off == 0 ? a.b_off : 0, tw, roots, st_radix, st_mag_t, st_mag_p,
+                                st_t, st_tws, tid);
+    }
+    const float2 *res = pfb_lds + res_off;
+    fft_stamp(5);
+
+    // ---- 4. bin selection and output ----
+    const float inv_m = 1.f / (float)len;
+    for (int g = tid; g < G * a.n_out; g += NT) {
+        const int fr = fdiv(g, a.mag_nout), u = g - fr * a.n_out;
+        if (fr < Gw) {
+            const int bin = a.sel ? a.sel[u] : u;
+            float2 v = res[fr * len + bin];
+            if (a.chirp) {
+                // X[k] = conj(chirp[k]) * conj(e[k]) / m
+                const float2 ch = a.chirp[bin];
+                const float2 r = cmul(mk2(ch.x, -ch.y), mk2(v.x, -v.y));
+                v = mk2(r.x * inv_m, r.y * inv_m);
+            }
+            a.out[(size_t)(f0 + fr) * a.n_out + u] = v;
+        }
+    }
+    fft_stamp(7);
+}
+
+
 inline unsigned grid_for(long long total) { return (unsigned)((total + 255) / 256); }
 
 template <int R>
@@ -708,9 +1208,135 @@ int pfb_lds_plan(int n, int *radices) {
     return cnt <= 16 ? cnt : -1;
 }
 
+// Shape of the run-per-compute-unit kernel for frames of nfft points transformed at length `len` (nfft, or
+// Bluestein's m): frames per workgroup G (at most `want`), the offset and size of the second LDS buffer, whether
+// the twiddle table fits beside them.  False when not even one frame fits.
+static bool pfb_cu_shape(int nfft, int avg, int len, int want, int &G, int &b_off, int &b_len, int &twl, size_t &bytes) {
+    for (G = want < 1 ? 1 : want; G >= 1; --G) {
+        if ((long long)G * nfft > (long long)kPfbCuPts * kPfbCuThreads) continue;
+        const long long al = ((long long)G * len + 1) & ~1LL;                 // even: 16-byte LDS stores into the buffer behind
+        long long bl = (long long)(G + avg - 1) * nfft;
+        if (bl < (long long)G * len) bl = (long long)G * len;
+        bl = (bl + 1) & ~1LL;
+        for (twl = len <= kPfbLdsTwMaxN ? 1 : 0; twl >= 0; --twl) {
+            const long long total = (al + bl + kPfbLdsMaxPrime + 1 + (twl ? len : 0)) * (long long)sizeof(float2);
+            if (total <= kPfbCuMaxBytes) {
+                b_off = (int)al;
+                b_len = (int)bl;
+                bytes = (size_t)total;
+                return true;
+            }
+        }
+    }
+    return false;
+}
+
+bool pfb_cu_fits(int nfft, int avg, int len) {
+    int G, bo, bl, twl;
+    size_t bytes;
+    return nfft >= 1 && avg >= 1 && len >= nfft && len <= kPfbLdsMaxN && pfb_cu_shape(nfft, avg, len, 1, G, bo, bl, twl, bytes);
+}
+
+static hipError_t launch_pfb_cu(const float2 *carry, int new_0, const float2 *in, const float *window, const float2 *tw,
+                                int nfft, int avg, int frames_n, const int *sel, int n_out, float2 *out,
+                                float2 *carry_out, int spare_begin, int spare_n, const FftPlan *blue, hipStream_t st,
+                                bool &taken) {
+    taken = false;
+    PfbCuArgs a{};
+    const int len = blue ? blue->m : nfft;
+    if (blue) {
+        if (blue->n != nfft || blue->m < 2 * nfft - 1 || blue->n_radices > 16 || !blue->d_chirp || !blue->d_bhat)
+            return hipErrorInvalidValue;
+        a.n_radices = blue->n_radices;
+        for (int i = 0; i < a.n_radices; ++i) a.radices[i] = blue->radices[i];
+    } else {
+        a.n_radices = pfb_lds_plan(nfft, a.radices);
+        if (a.n_radices < 0) return hipSuccess;            // not this kernel's length
+    }
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return hipErrorInvalidDevice;
+    static std::atomic<int> cu_count[64];
+    if (cu_count[dev].load() == 0) {
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        cu_count[dev].store(cus);
+    }
+    cus = cu_count[dev].load();
+    // one workgroup per compute unit: G consecutive frames each (frames_n == 0: a launch that only copies the carry)
+    int want = frames_n > 0 ? (frames_n + cus - 1) / cus : 1;
+    size_t lds = 0;
+    if (!pfb_cu_shape(nfft, avg, len, want, a.G, a.b_off, a.b_len, a.twl, lds)) return hipSuccess;    // does not fit: the caller's other kernel
+    a.carry = carry; a.in = in; a.window = window; a.tw = tw; a.sel = sel; a.out = out; a.carry_out = carry_out;
+    a.chirp = blue ? blue->d_chirp : nullptr;
+    a.bhat = blue ? blue->d_bhat : nullptr;
+    a.n = nfft; a.F = avg; a.frames_n = frames_n; a.n_out = n_out; a.new_0 = new_0; a.len = len;
+    a.spare_begin = spare_begin; a.spare_n = spare_n;
+    a.main_blocks = (unsigned)((frames_n + a.G - 1) / a.G);
+    auto magic = [](long long d) { return d <= 1 ? 0u : (unsigned)(0x100000000ULL / (unsigned long long)d + 1ULL); };
+    a.mag_n = magic(nfft);
+    a.mag_nout = magic(n_out);
+    a.mag_len = magic(len);
+    a.mag_pad = magic(len - nfft);
+    {
+        int p = 1;
+        for (int s = 0; s < a.n_radices; ++s) {
+            a.mag_t[s] = magic(len / a.radices[s]);
+            a.mag_p[s] = magic(p);
+            a.stage_t[s] = len / a.radices[s];
+            a.stage_tws[s] = len / (p * a.radices[s]);
+            p *= a.radices[s];
+        }
+        if (a.n_radices > 0 && a.radices[0] > 13) {
+            const int R = a.radices[0];
+            a.mag_ht = magic((long long)((R - 1) / 2 + 1) * (len / R));
+        }
+    }
+    a.blocks_per_xcd = (a.main_blocks + 7u) / 8u;
+    const unsigned spare_blocks = (unsigned)((spare_n + 2047) / 2048);
+    taken = true;
+    if (a.main_blocks + spare_blocks == 0) return hipSuccess;
+    static std::atomic<unsigned long long> attr_done{0};
+    if (!(attr_done.load() >> dev & 1ULL)) {
+        for (const void *f : {reinterpret_cast<const void *>(pfb_cu_kernel<true>), reinterpret_cast<const void *>(pfb_cu_kernel<false>)}) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kPfbCuMaxBytes);
+            if (e != hipSuccess) return e;
+        }
+        attr_done.fetch_or(1ULL << dev);
+    }
+    void *kargs[] = {&a};
+    const void *fn = a.twl ? reinterpret_cast<const void *>(pfb_cu_kernel<true>) : reinterpret_cast<const void *>(pfb_cu_kernel<false>);
+    return hipLaunchKernel(fn, dim3(a.blocks_per_xcd * 8u + spare_blocks), dim3(kPfbCuThreads), kargs, lds, st);
+}
+
 hipError_t launch_pfb_lds(const float2 *carry, int new_0, const float2 *in, const float *window, const float2 *tw,
                           int nfft, int avg, int frames_n, const int *sel, int n_out, float2 *out,
-                          float2 *carry_out, int spare_begin, int spare_n, long long window_len, hipStream_t st) {
+                          float2 *carry_out, int spare_begin, int spare_n, long long window_len, hipStream_t st,
+                          const FftPlan *blue) {
+    if (avg < 1 || frames_n < 0 || n_out < 1 || new_0 < 0 || spare_n < 0 || spare_begin < 0 || nfft < 1 ||
+        !in || !window || !tw || !out || (new_0 > 0 && !carry) || (spare_n > 0 && !carry_out) || (!sel && n_out != nfft))
+        return hipErrorInvalidValue;
+    // every read stays inside the logical window [carry | in]
+    if ((frames_n > 0 && (long long)(frames_n + avg - 1) * nfft > window_len) ||
+        (long long)spare_begin + spare_n > window_len || new_0 > window_len || window_len > 0x7fffffffLL - nfft)
+        return hipErrorInvalidValue;
+    // A run of frames per compute unit (round 3) when the run fits the LDS and the length has a stage other than
+    // radix 4 / 2 -- a prime above 13 (its stage runs on the matrix cores there), 3, 5, 7 ... -- or goes through
+    // Bluestein: measured per 1 M-sample buffer (profiles/r03_pfb_sweep.log) 1230 points 19.7 -> 15.5 us, 1016
+    // 21.5 -> 16.1, 1000 15.7 -> 14.5; pure powers of two are 3 - 8 % FASTER a frame per workgroup (1024: 12.7
+    // against 13.1 us, 64 ... 256: 10.0 / 10.8 against 10.7 / 11.6) and stay there.  GSDR_PFB_CU=0 / 1 forces.
+    static const int cu_mode = [] { const char *e = std::getenv("GSDR_PFB_CU"); return e && e[0] ? (e[0] == '0' ? 0 : 1) : -1; }();
+    bool cu_wanted = cu_mode == 1 || blue != nullptr;
+    if (cu_mode < 0 && !blue) {
+        int r[16];
+        const int nr = pfb_lds_plan(nfft, r);
+        for (int i = 0; i < nr; ++i) cu_wanted |= (r[i] != 4 && r[i] != 2);
+    }
+    if (cu_wanted) {
+        bool taken = false;
+        const hipError_t e = launch_pfb_cu(carry, new_0, in, window, tw, nfft, avg, frames_n, sel, n_out, out, carry_out,
+                                           spare_begin, spare_n, blue, st, taken);
+        if (e != hipSuccess || taken) return e;
+        if (blue) return hipErrorInvalidValue;             // only the run kernel knows Bluestein's identity
+    }
     PfbLdsArgs a{};
     a.n_radices = pfb_lds_plan(nfft, a.radices);
     if (a.n_radices < 0 || avg < 1 || frames_n < 0 || n_out < 1 || new_0 < 0 || spare_n < 0 || spare_begin < 0 ||
@@ -776,6 +1402,21 @@ hipError_t launch_pfb_lds(const float2 *carry, int new_0, const float2 *in, cons
 }
 
 const char *pfb_lds_kernel_name() { return "pfb_lds_kernel"; }
+const char *pfb_cu_kernel_name() { return "pfb_cu_kernel"; }
+// which of the two kernels launch_pfb_lds() runs for this shape (describe(), the profiler's name)
+bool pfb_cu_takes(int nfft, int avg, int len, bool bluestein) {
+    static const int cu_mode = [] { const char *e = std::getenv("GSDR_PFB_CU"); return e && e[0] ? (e[0] == '0' ? 0 : 1) : -1; }();
+    if (!bluestein) {
+        int r[16];
+        const int nr = pfb_lds_plan(nfft, r);
+        if (cu_mode == 0 || nr < 0) return false;
+        bool wanted = cu_mode == 1;
+        for (int i = 0; i < nr; ++i) wanted |= (r[i] != 4 && r[i] != 2);
+        if (!wanted) return false;
+    }
+    return pfb_cu_fits(nfft, avg, len);
+}
+
 const char *fft_kernel_name() { return "fft_pass_kernel"; }
 
 }  // namespace gsdr

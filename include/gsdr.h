@@ -205,12 +205,14 @@ void gsdr_vna_helper_update(gsdr_vna_helper *v);
 void gsdr_pfb_tone_bins(int rate, int fft_tones, const int *freq, int n, int *bins);
 /* ref: cpp/USRP_demodulator.cpp:706 */
 int gsdr_pfb_batching(long long buffer_len, int fft_tones, long long pf_average);
-/* Which frame lengths TONES / NOISE run as one launch per buffer (polyphase filter + FFT inside the LDS +
- * bin selection, a frame per workgroup): writes the radices of the in-LDS transform of an fft_tones-point
- * frame into radices[0..15] in stage order and returns their number, or -1 when the length does not fit
- * (more than 8192 points, a prime factor above 127): such TONES frames run as one DDC per selected bin,
- * such NOISE frames through the global-memory FFT stages.  Host only.  Replaces the reference's
- * cufftPlanMany for the PFB (ref: cpp/USRP_demodulator.cpp:149-152, :292-295). */
+/* The radix stages of the in-LDS transform of an fft_tones-point frame (TONES / NOISE as one launch per buffer:
+ * polyphase filter + FFT inside the LDS + bin selection): writes the radices into radices[0..15] in stage order and
+ * returns their number, or -1 when the length has no such plan (more than 8192 points, a prime factor above 127).
+ * Such lengths up to 4096 points still run inside the LDS, through Bluestein's identity at the padded length
+ * 2^ceil(log2(2 fft_tones - 1)); longer ones through the global-memory FFT stages -- for TONES and NOISE alike
+ * (round 3: every TONES frame length takes filter + FFT + selection, as the reference's cufftPlanMany takes any
+ * fft_tones).  Host only.  Replaces the reference's cufftPlanMany for the PFB
+ * (ref: cpp/USRP_demodulator.cpp:149-152, :292-295). */
 int gsdr_pfb_lds_stages(int fft_tones, int *radices);
 
 /* ref: struct chirp_parameter, headers/kernels.cuh:58-64 and its derivation

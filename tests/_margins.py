@@ -6,12 +6,19 @@ import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MARGINS = {}
+INFO = {}        # figures recorded beside the errors (durations, ratios): never part of "worst"
 
 
 def record_margin(value, label=None):
     test = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
     key = test if not label else f"{test} :: {label}"
     MARGINS[key] = max(MARGINS.get(key, 0.0), float(value))
+
+
+def record_info(value, label):
+    test = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
+    key = f"{test} :: {label}"
+    INFO[key] = max(INFO.get(key, 0.0), float(value))
 
 
 def write_margins(exitstatus=0):
@@ -25,7 +32,8 @@ def write_margins(exitstatus=0):
            "worst": max(MARGINS.values()), "worst_at": max(MARGINS, key=MARGINS.get), "tests": len(MARGINS),
            "exit_status": int(exitstatus),
            "worst_per_test_function": dict(sorted(summary.items(), key=lambda t: -t[1])),
-           "per_test": dict(sorted(MARGINS.items(), key=lambda t: -t[1]))}
+           "per_test": dict(sorted(MARGINS.items(), key=lambda t: -t[1])),
+           "other_figures": dict(sorted(INFO.items()))}
     out_dir = os.path.join(ROOT, "gpurun_out")
     try:
         os.makedirs(out_dir, exist_ok=True)

@@ -12,7 +12,7 @@ import os
 import numpy as np
 import pytest
 
-from _margins import record_margin
+from _margins import record_info, record_margin
 
 pytestmark = pytest.mark.gpu
 
@@ -423,7 +423,7 @@ def test_direct_high_dynamic_range_comb(cuda_device, gsdr_lib, oracle_mod, monke
     record_margin(worst_strong, "strong half of the comb")
     record_margin(worst_weak, f"weak half of the comb (down to -{span_db} dB)")
     record_margin(worst_weak32, f"weak half of the comb, the reference's fp32 order on the CPU (oracle/recipe_b.py, complex64)")
-    record_margin(worst_ratio, "largest per-tone ratio HIP error / fp32-restatement error (both against the fp64 oracle)")
+    record_info(worst_ratio, "largest per-tone ratio HIP error / fp32-restatement error (both against the fp64 oracle)")
     record_margin(worst_all, "all tones together (error against the comb's total power)")
     assert worst_strong <= TOL, worst_strong
     assert worst_all <= 1e-6, worst_all
@@ -450,7 +450,7 @@ def test_tones_high_dynamic_range_comb(cuda_device, gsdr_lib, oracle_mod, monkey
     ampl = (10.0 ** (-np.linspace(0.0, span_db, N) / 20.0)).astype(np.float32)
     phase = rng.uniform(0, 2 * np.pi, N).astype(np.float32)
     dem = make_pfb(freq, rate, nfft, F, L)
-    assert dem.kernel_name == ("pfb_lds_kernel" if path == "fft" else dem.kernel_name) and \
+    assert (dem.kernel_name in PFB_LDS_KERNELS if path == "fft" else True) and \
         (path == "fft" or dem.kernel_name.startswith("ddc_mfma"))
     ref = oracle_mod.Pfb(freq, rate, nfft, F, L)
     np.testing.assert_array_equal(dem.bins(), ref.bins())
@@ -713,6 +713,35 @@ def test_noise_full_spectrum_parity(cuda_device, gsdr_lib, oracle_mod, monkeypat
     dem.close()
 
 
+@pytest.mark.parametrize("nfft", [2 * 509, 4 * 251, 1021], ids=lambda v: "nfft%d" % v)
+def test_tones_frames_with_a_large_prime_factor_take_the_fft_path(cuda_device, gsdr_lib, oracle_mod, nfft):
+    """The reference takes ANY fft_tones through one cufftPlanMany (ref: cpp/USRP_demodulator.cpp:150-153).  Frames of
+    up to 8192 points with a prime factor above 127 ran as one DDC per selected bin until round 2; now they take
+    filter + FFT + selection like every other length -- Bluestein's identity inside the LDS, one launch per buffer.
+    1 M-sample buffers at 200 Msps, 64 tones, four buffers against the oracle (lengths exact, <= 1e-5 per tone),
+    and the launch duration by hipEvents on its stream: at most 60 us per buffer."""
+    rate, N, F, L, nbuf = 200_000_000, 64, 4, 1_000_000, 4
+    rng = np.random.default_rng(nfft)
+    bins = rng.choice(np.arange(nfft), size=N, replace=False)
+    freq = [int((b if b < nfft // 2 else b - nfft) * (rate / nfft)) for b in bins]
+    dem = make_pfb(freq, rate, nfft, F, L)
+    assert dem.kernel_name == "pfb_cu_kernel", dem.kernel_name
+    ref = oracle_mod.Pfb(freq, rate, nfft, F, L)
+    np.testing.assert_array_equal(dem.bins(), ref.bins())
+    dem.profile_enable(1)
+    for c in range(nbuf):
+        x = crandn(rng, L)
+        y = run_device(dem, x, cuda_device)
+        yr = ref.process(x)
+        assert y.size == yr.size and yr.size
+        assert rel_err_per_tone(y.reshape(-1, N), yr.reshape(-1, N)).max() <= TOL
+    kn, kms = dem.profile_read()
+    dem.close()
+    us = kms / kn * 1e3
+    record_info(us, "launch duration per 1 M-sample buffer in us (hipEvents)")
+    assert kn == nbuf and us <= 60.0, us
+
+
 NOISE_FFT_CASES = [
     # nfft, avg, L, buffers                      stages
     (16, 3, 200, 4),                           # 4 4
@@ -731,6 +760,12 @@ NOISE_FFT_CASES = [
     (131 * 4, 2, 20_000, 2),                   # 524: prime factor 131 > 127 -> not for the in-LDS kernel
     (101, 2, 5_000, 3),                        # a prime frame: one stage, one column per frame, 11 frames per workgroup
     (2 * 17, 3, 3_000, 3),                     # 34: 31 frames per workgroup, prime-first stage with two columns
+    (2 * 509, 4, 60_000, 3),                   # 1018: prime factor 509 -> Bluestein through 2048 inside the LDS (round 3)
+    (4 * 251, 3, 50_000, 3),                   # 1004: the same through 2048
+    (1021, 2, 30_000, 3),                      # a prime frame through 2048
+    (3 * 1009, 2, 40_000, 3),                  # 3027 -> 8192: the longest Bluestein length the LDS takes
+    (2048, 4, 100_000, 2),                     # two frames per compute unit at most: the run kernel's LDS limit
+    (4096, 4, 100_000, 2),                     # a frame does not fit the run kernel: the frame-per-workgroup kernel
 ]
 
 
@@ -765,15 +800,26 @@ def test_tones_long_frames(cuda_device, gsdr_lib, oracle_mod, monkeypatch, nfft,
     dem.close()
 
 
-def pfb_lds_fits(nfft):
-    """lengths the frame-per-workgroup kernel takes: <= 8192 points, no prime factor above 127"""
+PFB_LDS_KERNELS = ("pfb_cu_kernel", "pfb_lds_kernel")     # a run of frames per compute unit / a frame per workgroup
+
+
+def pfb_lds_fits(nfft, avg=4):
+    """Lengths TONES / NOISE run inside the LDS in one launch: up to 8192 points without a prime factor above 127
+    (radix stages over the frame length), or -- round 3 -- any length whose Bluestein length m = 2^ceil(log2(2n-1))
+    is at most 8192 and fits the run kernel's LDS layout (a buffer of m points plus one of max(m, avg*n))."""
     m, q, largest = nfft, 2, 1
     while m > 1:
         while m % q == 0:
             m //= q
             largest = q
         q += 1
-    return nfft <= 8192 and largest <= 127
+    if nfft <= 8192 and largest <= 127:
+        return True
+    mm = 1
+    while mm < 2 * nfft - 1:
+        mm *= 2
+    even = lambda v: (v + 1) & ~1
+    return mm <= 8192 and (even(mm) + even(max(mm, avg * nfft)) + 128) * 8 <= 156 * 1024
 
 
 @pytest.mark.parametrize("path", ["lds", "global"])
@@ -792,7 +838,10 @@ def test_noise_fft_stage_parity(cuda_device, gsdr_lib, oracle_mod, monkeypatch, 
     p = g.param(mode="RX", rate=1_000_000, buffer_len=L, decim=0, pf_average=avg, fft_tones=nfft,
                 freq=[0], wave_type=[g.w_type.NOISE])
     dem = g.RX_buffer_demodulator(p, device_index=0)
-    assert dem.kernel_name == ("pfb_lds_kernel" if path == "lds" and pfb_lds_fits(nfft) else "fft_pass_kernel")
+    if path == "lds" and pfb_lds_fits(nfft, avg):
+        assert dem.kernel_name in PFB_LDS_KERNELS
+    else:
+        assert dem.kernel_name == "fft_pass_kernel"
     ref = oracle_mod.Noise(nfft, avg, L)
     assert dem.out_capacity == nfft * ref.batching
     for c in range(nbuf):
@@ -1267,7 +1316,7 @@ def test_pipelined_submit_device_tones(cuda_device, gsdr_lib, oracle_mod, monkey
     rng = np.random.default_rng(2718)
     freq = rng.choice(np.arange(-rate // 2 + 1, rate // 2), size=N, replace=False)
     a, b = make_pfb(freq, rate, nfft, F, L), make_pfb(freq, rate, nfft, F, L)
-    assert b.kernel_name == "pfb_lds_kernel" if streams == "fft" else b.kernel_name.startswith("ddc_mfma")
+    assert b.kernel_name in PFB_LDS_KERNELS if streams == "fft" else b.kernel_name.startswith("ddc_mfma")
     ref = oracle_mod.Pfb(freq, rate, nfft, F, L)
     scales = [1.0, 1e-3, 50.0, 1.0, 1e-2, 1.0, 7.0, 1.0, 1.0]
     xs = [torch.from_numpy((crandn(rng, L) * np.float32(sc)).astype(np.complex64)).to(cuda_device) for sc in scales]
@@ -1396,9 +1445,9 @@ def test_pipelined_fuzz_random_shapes(cuda_device, gsdr_lib, monkeypatch, rt, to
             L = int(M * rng.integers(max(F, 4), 400))
             mk = lambda: make_direct(freq, rate, M, F, L)
         a, b = mk(), mk()
-        ran_mfma += b.kernel_name.startswith("ddc_mfma") or b.kernel_name == "pfb_lds_kernel"
+        ran_mfma += b.kernel_name.startswith("ddc_mfma") or b.kernel_name in PFB_LDS_KERNELS
         if it % 3 == 2 and tones == "fft":
-            assert b.kernel_name == "pfb_lds_kernel"
+            assert b.kernel_name in PFB_LDS_KERNELS
         xs = [torch.from_numpy((crandn(rng, L) * np.float32(10.0 ** rng.integers(-3, 3))).astype(np.complex64))
               .to(cuda_device) for _ in range(7)]
         out_a = torch.empty(a.out_capacity, dtype=torch.complex64, device=cuda_device)
