@@ -138,3 +138,52 @@ def test_single_vna_over_tcp(server):
     got = np.concatenate(got)
     assert got.shape == want.shape
     assert np.linalg.norm(got - want) / np.linalg.norm(want) <= 1e-5
+
+
+def test_two_front_ends_in_one_command_and_burst_buffer_length(server):
+    """A_RX2 (DIRECT, fed by the A_TXRX tone comb) and B_RX2 (CHIRP, fed by the B_TXRX chirp) active in ONE command:
+    the reference builds a demodulator per front-end and runs a link thread each (ref:
+    cpp/USRP_server_link_threads.cpp:121,136,325-336); their packets share the data socket -- tagged 'B' for
+    front-end A and 'D' for B (ref: cpp/USRP_hardware_manager.cpp:1413-1418), each with its own packet counter --
+    and the EOM comes after both are done.  Front-end B is in burst mode: its buffer is one burst long,
+    buffer_len = burst_on * rate (ref: link_threads.cpp:99-102), whatever the command's buffer_len says.
+    Payloads against the oracle chains, <= 1e-5 per channel."""
+    from make_commands import get_noise_direct, single_vna
+    asyn, data = server
+    tones = [-40000000 + 5000000 * k + 1234 for k in range(16)]
+    cmd = get_noise_direct(tones, 100000000, 0.03, 100, 300e6)                    # A: 3 buffers of 1 M samples
+    vna = single_vna(-80000000, 80000000, 0.01, 10000, 200000000, 300e6, amplitude=0.5)   # B: 2 M samples
+    for key_b, key_a in (("B_TXRX", "A_TXRX"), ("B_RX2", "A_RX2")):
+        cmd[key_b] = dict(vna[key_a], burst_on=0.0025, burst_off=0.001)           # bursts of 500 000 samples
+    send_command(asyn, cmd)
+    assert recv_async(asyn) == {"type": "ack", "payload": "Message received"}
+    got = {b"B": [], b"D": []}
+    want_packets = {b"B": 3, b"D": 4}
+    while any(len(got[c]) < want_packets[c] for c in got):
+        h = np.frombuffer(recv_all(data, 21), dtype=HEADER)[0]
+        code = bytes(h["front_end_code"])
+        assert code in got and h["usrp_number"] == 0 and h["errors"] == 0
+        assert h["packet_number"] == len(got[code])                                # a counter per front-end
+        assert h["channels"] == (16 if code == b"B" else 1)
+        assert h["length"] == (16 * 10000 if code == b"B" else 2500)               # B: 500 000 samples / ppt 200
+        got[code].append(np.frombuffer(recv_all(data, int(h["length"]) * 8), dtype=np.complex64))
+    reply = recv_async(asyn)
+    assert reply["type"] == "ack" and "EOM" in reply["payload"]
+    import oracle
+    oracle.build()
+    # front-end A: the TX tone comb into the DIRECT demodulator
+    rate, L = 100000000, 1000000
+    ref = oracle.Direct(tones, rate, 100, cmd["A_RX2"]["pf_average"], L)
+    want = np.concatenate([ref.process(oracle.tone_gen(tones, [1.0 / 16] * 16, rate, k * L, L)) for k in range(3)])
+    y = np.concatenate(got[b"B"]).reshape(-1, 16)
+    assert (np.linalg.norm(y - want, axis=0) / np.linalg.norm(want, axis=0)).max() <= 1e-5
+    # front-end B: the TX chirp (the TX side's own parameter derivation) into the chirp demodulator + lock-in,
+    # in buffers of one burst
+    rate, L = 200000000, 500000
+    rx = cmd["B_RX2"]
+    cp = oracle.chirp_params_tx(rate, rx["freq"][0], rx["chirp_f"][0], rx["swipe_s"][0], rx["chirp_t"][0])
+    refc = oracle.Chirp(rate, rx["freq"][0], rx["chirp_f"][0], rx["swipe_s"][0], rx["chirp_t"][0], rx["decim"], L)
+    wantc = np.concatenate([refc.process(oracle.chirp_gen(cp, k * L, L, 0.5)) for k in range(4)])
+    gotc = np.concatenate(got[b"D"])
+    assert gotc.shape == wantc.shape
+    assert np.linalg.norm(gotc - wantc) / np.linalg.norm(wantc) <= 1e-5
