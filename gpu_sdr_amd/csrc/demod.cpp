@@ -334,11 +334,13 @@ int setup_ddc_common(gsdr_demod *h, int F, int M, unsigned rate,
     h->pipe = allow_flat && env_int("GSDR_DDC_PIPE", 1) != 0 && F <= 4 && env_int("GSDR_DDC_MFMA", 1) == 0;
     if (h->pipe) {
         // sub-block length: whole sub-blocks per block, cheapest total
-        // (padded samples + ~3.3 sample-equivalents of fold work per sub-block)
+        // (padded samples + ~3.3 sample-equivalents of fold work per sub-block).  40 since round 3: half the
+        // folds and phasor steps of 20 at 124 instead of 82 registers (4 waves per SIMD instead of 5):
+        // C3 460 -> 440 us in order (profiles/r03_flat_k.log)
         int forced = env_int("GSDR_DDC_K", 0);
-        if (forced != 12 && forced != 16 && forced != 20) forced = 0;
+        if (forced != 12 && forced != 16 && forced != 20 && forced != 40) forced = 0;
         double best = 1e300;
-        for (int k : {20, 16, 12}) {
+        for (int k : {40, 20, 16, 12}) {
             if (forced && forced != k) continue;
             const long long nsub = (M + k - 1) / k;
             const double cost = (double)nsub * (k + 3.3);

@@ -159,7 +159,7 @@ DIRECT_CASES = [
 
 
 @pytest.mark.parametrize("case", DIRECT_CASES, ids=lambda c: "N%d_M%d_F%d_L%d" % (c[0], c[2], c[3], c[4]))
-@pytest.mark.parametrize("impl", ["flat", "flat12", "flat16", "flat20", "simple16", "simple32",
+@pytest.mark.parametrize("impl", ["flat", "flat12", "flat16", "flat20", "flat40", "simple16", "simple32",
                                   "mfma", "mfma_rt2", "mfma16", "mfma16_rt2", "mfma16w8", "mfma16p", "mfma_c", "mfma_t2",
                                   "mfma_w2", "mfma_pk16"])
 def test_direct_parity(cuda_device, gsdr_lib, oracle_mod, monkeypatch, case, impl):

@@ -19,7 +19,7 @@ import os
 BASE = 52                      # first private SGPR
 XA, TA = BASE, BASE + 8        # set A: x s[52:59], taps s[60:75]
 XB, TB = BASE + 24, BASE + 32  # set B: x s[76:83], taps s[84:99]
-SIZES = {12: [4, 4, 2, 2], 16: [4, 4, 4, 4], 20: [4, 4, 4, 4, 2, 2]}
+SIZES = {12: [4, 4, 2, 2], 16: [4, 4, 4, 4], 20: [4, 4, 4, 4, 2, 2], 40: [4] * 10}
 LOADOP = {2: "s_load_dwordx2", 4: "s_load_dwordx4", 8: "s_load_dwordx8", 16: "s_load_dwordx16"}
 
 
@@ -146,7 +146,7 @@ def main():
              "template <int F> __device__ __forceinline__ void prime_set_a(const void *xp, const void *tp);\n"]
     for F in (1, 2, 3, 4):
         parts.append(prime(F))
-        for PK in (12, 16, 20):
+        for PK in (12, 16, 20, 40):
             parts.append(subblock(F, PK))
     with open(dst, "w") as f:
         f.write("\n".join(parts))
