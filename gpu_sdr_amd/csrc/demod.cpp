@@ -166,6 +166,7 @@ struct gsdr_demod {
     // ---- TONES / NOISE, a frame per workgroup: filter + in-LDS transform + bin selection (fft_kernels.hip) ----
     bool pfb_lds = false;
     bool pfb_blue = false;                           // ... through Bluestein's identity (h->fft holds chirp, transform, twiddles)
+    bool pfb_cu = false;                             // ... by the run-per-compute-unit kernel (pfb_cu_kernel)
     float2 *d_pfb_tw = nullptr;                      // w_nfft^k
     int *d_pfb_sel = nullptr;                        // TONES: bin of every output column
     float2 *d_pfb_carry[kStageSets] = {};            // the samples a call leaves over (at most F*nfft)
@@ -876,7 +877,18 @@ int enqueue_pfb_lds(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t st
     const gsdr::FftPlan *blue = h->pfb_blue ? &h->fft : nullptr;
     const float2 *tw = h->pfb_blue ? h->fft.d_tw : h->d_pfb_tw;
     hipEvent_t stop = nullptr;
-    if (h->pipe_overlap) {
+    // (the run-per-compute-unit kernel fills every unit with one workgroup and most of its LDS: two of its launches
+    //  cannot share the chip, so splitting off the carry copy only adds a launch and an event -- 16.4 us per buffer in
+    //  one launch against 17.7 split, profiles/r03_bench_default.json -- and its calls stay whole)
+    const bool split = h->pipe_overlap && !h->pfb_cu;
+    if (h->pipe_overlap && !split) {
+        if (record_begin(h, st, &stop)) return -1;
+        HIPCHK(h, gsdr::launch_pfb_lds(carry, h->bh.new_0, in, h->d_fft_win, tw, h->nfft, h->F, cb,
+                                       sel, h->ddc_channels, out, carry_out, h->bh.spare_begin, spare_n, wlen, st, blue));
+        if (stop) HIPCHK(h, hipEventRecord(stop, st));
+        stop = nullptr;
+        HIPCHK(h, hipEventRecord(h->ev_abs[h->pipe_seq % 4], st));
+    } else if (split) {
         // overlapped entry: consecutive buffers run on the compute streams in turn.  What ties them
         // together is the carry alone: a launch of its own copies this call's leftovers first (it needs
         // the previous call's carry and this buffer, nothing of this call's frames), its event lets the
@@ -1192,8 +1204,8 @@ gsdr_demod *gsdr_demod_create(const gsdr_param_c *p) {
                 h->pfb_blue = blue_ok;
                 h->F = F;
                 h->M = h->nfft;
-                h->kernel_name = gsdr::pfb_cu_takes(h->nfft, F, blue_ok ? (int)blue_m : h->nfft, blue_ok) ? gsdr::pfb_cu_kernel_name()
-                                                                                                          : gsdr::pfb_lds_kernel_name();
+                h->pfb_cu = gsdr::pfb_cu_takes(h->nfft, F, blue_ok ? (int)blue_m : h->nfft, blue_ok);
+                h->kernel_name = h->pfb_cu ? gsdr::pfb_cu_kernel_name() : gsdr::pfb_lds_kernel_name();
                 std::vector<float2> tw((size_t)h->nfft);
                 for (int k = 0; k < h->nfft; ++k) {
                     const double a = -2.0 * M_PI * (double)k / (double)h->nfft;

@@ -60,6 +60,38 @@ __device__ __forceinline__ void butterfly(float2 (&u)[R], const float2 *__restri
         u[2] = mk2(a0.x - b0.x, a0.y - b0.y);
         u[1] = mk2(a1.x + b1.y, a1.y - b1.x);   // a1 - i*b1
         u[3] = mk2(a1.x - b1.y, a1.y + b1.x);   // a1 + i*b1
+    } else if constexpr (R == 16) {
+        // DFT-16 as 4 x 4 (round 3): r = r0 + 4 r1, q = q1 + 4 q0,
+        //     X[q1 + 4 q0] = sum_r0 w4^(q0 r0) [ w16^(q1 r0) sum_r1 w4^(q1 r1) x[r0 + 4 r1] ]
+        // -- two levels of radix-4 butterflies in registers with nine constant twiddles between them: one LDS (or
+        // memory) round trip, one barrier and one set of index arithmetic where two radix-4 stages have two
+        float2 y[4][4];
+#pragma unroll
+        for (int r0 = 0; r0 < 4; ++r0) {
+            float2 v[4] = {u[r0], u[r0 + 4], u[r0 + 8], u[r0 + 12]};
+            butterfly<4>(v, tw, n);
+#pragma unroll
+            for (int q1 = 0; q1 < 4; ++q1) y[r0][q1] = v[q1];
+        }
+        // w16^m = (cos, -sin)(2 pi m / 16), m = q1 r0
+        constexpr float c1 = 0.92387953251128673848f, s1 = 0.38268343236508978178f, h = 0.70710678118654752440f;
+        auto mulc = [](float2 a, float wr, float wi) { return mk2(a.x * wr - a.y * wi, a.x * wi + a.y * wr); };
+        y[1][1] = mulc(y[1][1], c1, -s1);      // m = 1
+        y[1][2] = mulc(y[1][2], h, -h);        // m = 2
+        y[1][3] = mulc(y[1][3], s1, -c1);      // m = 3
+        y[2][1] = mulc(y[2][1], h, -h);        // m = 2
+        y[2][2] = mk2(y[2][2].y, -y[2][2].x);  // m = 4: -i
+        y[2][3] = mulc(y[2][3], -h, -h);       // m = 6
+        y[3][1] = mulc(y[3][1], s1, -c1);      // m = 3
+        y[3][2] = mulc(y[3][2], -h, -h);       // m = 6
+        y[3][3] = mulc(y[3][3], -c1, s1);      // m = 9
+#pragma unroll
+        for (int q1 = 0; q1 < 4; ++q1) {
+            float2 v[4] = {y[0][q1], y[1][q1], y[2][q1], y[3][q1]};
+            butterfly<4>(v, tw, n);
+#pragma unroll
+            for (int q0 = 0; q0 < 4; ++q0) u[q1 + 4 * q0] = v[q0];
+        }
     } else {
         // odd prime: out[q] = sum_r u[r] * w_R^(q r), roots from the table (n is a multiple of R)
         float2 root[R];
@@ -440,6 +472,7 @@ __global__ __launch_bounds__(NT) GSDR_NO_PK void pfb_lds_kernel(const PfbLdsArgs
             case 7: lds_stage<7>(src, dst, n, p, st, stw, mt, mp, tw, FR, tid, NT); break;
             case 11: lds_stage<11>(src, dst, n, p, st, stw, mt, mp, tw, FR, tid, NT); break;
             case 13: lds_stage<13>(src, dst, n, p, st, stw, mt, mp, tw, FR, tid, NT); break;
+            case 16: lds_stage<16>(src, dst, n, p, st, stw, mt, mp, tw, FR, tid, NT); break;
             default:
                 if (s == 0)
                     lds_stage_prime_first(R, src, dst, n, roots, st, mt, a.mag_t4, FR, tid, NT);
@@ -803,6 +836,7 @@ __device__ __forceinline__ int pfb_cu_stages(const PfbCuArgs &a, float2 *lds, in
             case 7: lds_stage<7>(src, dst, len, p, st, stw, mt, mp, tw, FR, tid, NT); break;
             case 11: lds_stage<11>(src, dst, len, p, st, stw, mt, mp, tw, FR, tid, NT); break;
             case 13: lds_stage<13>(src, dst, len, p, st, stw, mt, mp, tw, FR, tid, NT); break;
+            case 16: lds_stage<16>(src, dst, len, p, st, stw, mt, mp, tw, FR, tid, NT); break;
             default:
                 if (s == 0 && FR * st >= 64)            // many columns: fat tiles, a point per column
                     lds_stage_prime_first_mfma32(R, src, dst, len, roots, st, mt, FR, tid, NT);
@@ -987,14 +1021,16 @@ hipError_t launch_radix(int R, const float2 *x, float2 *y, int n, int p, const f
         case 7: return launch_pass<7>(x, y, n, p, tw, batch, st);
         case 11: return launch_pass<11>(x, y, n, p, tw, batch, st);
         case 13: return launch_pass<13>(x, y, n, p, tw, batch, st);
+        case 16: return launch_pass<16>(x, y, n, p, tw, batch, st);
         default: return hipErrorInvalidValue;
     }
 }
 
-// radices of n (4s first, then 2, then odd primes up to 13); empty when a larger prime remains
+// radices of n (16s, 4s, then 2, then odd primes up to 13); empty when a larger prime remains
 std::vector<int> factorize(int n) {
     std::vector<int> r;
     int m = n;
+    while (m % 16 == 0) { r.push_back(16); m /= 16; }      // (round 3) two radix-4 levels per pass through memory
     while (m % 4 == 0) { r.push_back(4); m /= 4; }
     for (int p : {2, 3, 5, 7, 11, 13})
         while (m % p == 0) { r.push_back(p); m /= p; }
@@ -1180,7 +1216,7 @@ hipError_t launch_pfb_filter(const float2 *raw, const float *window, int nfft, i
     return hipGetLastError();
 }
 
-// Stages of the in-LDS transform: 4s, 2, then every odd prime factor (3, 5, 7 with register
+// Stages of the in-LDS transform: 16s, 4s, 2, then every odd prime factor (3, 5, 7 with register
 // butterflies, any larger prime through the one-output-per-item stage).  Empty when n does not fit:
 // n > kPfbLdsMaxN, more than 16 stages, or a prime factor above kPfbLdsMaxPrime (its stage is O(R) per
 // output: a 1021-point prime frame would be a plain DFT).
@@ -1202,6 +1238,12 @@ int pfb_lds_plan(int n, int *radices) {
     if (m != 1) return -1;
     for (int i = nbig - 1; i >= 0; --i) push(big[i]);
     m = small;
+    // (round 3) two radix-4 levels per LDS round trip for frames of 4096 points and more: 4096 points 14.8 -> 13.3 us
+    // per buffer, 8192 27.0 -> 23.2.  A radix-16 butterfly keeps one thread in sixteen points busy: below 4096
+    // points too few waves are left to hide each other's latencies (1024 points: two radix-16 stages take the
+    // 4.8 us four radix-4 stages took, profiles/r03_stamp_pfb_cu.log; 64 points 10.0 -> 10.5 us)
+    if (n >= 4096)
+        while (m % 16 == 0) { push(16); m /= 16; }
     while (m % 4 == 0) { push(4); m /= 4; }
     for (int q : {2, 3, 5, 7, 11, 13})
         while (m % q == 0) { push(q); m /= q; }
@@ -1328,7 +1370,7 @@ hipError_t launch_pfb_lds(const float2 *carry, int new_0, const float2 *in, cons
     if (cu_mode < 0 && !blue) {
         int r[16];
         const int nr = pfb_lds_plan(nfft, r);
-        for (int i = 0; i < nr; ++i) cu_wanted |= (r[i] != 4 && r[i] != 2);
+        for (int i = 0; i < nr; ++i) cu_wanted |= (r[i] != 4 && r[i] != 2 && r[i] != 16);
     }
     if (cu_wanted) {
         bool taken = false;
@@ -1411,7 +1453,7 @@ bool pfb_cu_takes(int nfft, int avg, int len, bool bluestein) {
         const int nr = pfb_lds_plan(nfft, r);
         if (cu_mode == 0 || nr < 0) return false;
         bool wanted = cu_mode == 1;
-        for (int i = 0; i < nr; ++i) wanted |= (r[i] != 4 && r[i] != 2);
+        for (int i = 0; i < nr; ++i) wanted |= (r[i] != 4 && r[i] != 2 && r[i] != 16);
         if (!wanted) return false;
     }
     return pfb_cu_fits(nfft, avg, len);

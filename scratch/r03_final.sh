@@ -1,0 +1,8 @@
+#!/bin/bash
+# round-3 closing run: smoke(), the whole GPU suite (margins), the default bench line, the two-rank rehearsal
+mkdir -p gpurun_out
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+python -m pytest tests -m gpu -q > gpurun_out/r03_pytest.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/r03_pytest.log
+timeout -k 10 600 python bench.py > gpurun_out/r03_bench_default.json 2> gpurun_out/r03_bench_default.err; echo "bench rc=$?"
+timeout -k 10 300 python bench.py --gpus 2 --steps 100 --warmup 10 --no-extras --no-cpu > gpurun_out/r03_n2_one_device.json 2> gpurun_out/r03_n2_one_device.err; echo "n2 rc=$?"
+cut -c1-400 gpurun_out/r03_n2_one_device.json

@@ -1,9 +1,9 @@
-"""Reduces gpurun_out/prof_<wl>/ and prof_<wl>_io/ (scratch/prof_r02.sh) to the files committed under profiles/."""
+"""Reduces gpurun_out/prof_<wl>/ and prof_<wl>_io/ (scratch/prof_r03.sh) to the files committed under profiles/."""
 import collections, csv, glob, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "profiles")
-TAG = "r02"
+TAG = os.environ.get("PROF_TAG", "r03")
 
 
 def kname(full):
@@ -67,7 +67,7 @@ def dominant(stats):
     """the gsdr:: DDC / chirp kernel with the largest share of the in-order run"""
     best = None
     for k, v in (stats or {}).items():
-        if ("ddc_mfma" in k or "chirp" in k or "ddc_flat" in k or "pfb_lds" in k) and "convert" not in k:
+        if ("ddc_mfma" in k or "chirp" in k or "ddc_flat" in k or "pfb_lds" in k or "pfb_cu" in k) and "convert" not in k:
             if best is None or v[1] > best[1]:
                 best = (k, v[1])
     return best[0] if best else None
@@ -86,7 +86,7 @@ def kernel_stats2(src_dir, dst):
 
 
 traffic = {}
-for wl in ("c2", "c3", "pfb", "c4"):
+for wl in ("c2", "c3", "c3flat", "pfb", "c4"):
     src = os.path.join(ROOT, "gpurun_out", "prof_" + wl)
     if not os.path.isdir(src):
         continue
