@@ -60,6 +60,45 @@ __device__ __forceinline__ void butterfly(float2 (&u)[R], const float2 *__restri
         u[2] = mk2(a0.x - b0.x, a0.y - b0.y);
         u[1] = mk2(a1.x + b1.y, a1.y - b1.x);   // a1 - i*b1
         u[3] = mk2(a1.x - b1.y, a1.y + b1.x);   // a1 + i*b1
+    } else if constexpr (R == 8) {
+        // DFT-8 = two DFT-4 (even / odd inputs) + four constant twiddles: X[k] = E[k] + w8^k O[k], X[k+4] = E[k] - w8^k O[k]
+        float2 e[4] = {u[0], u[2], u[4], u[6]}, o[4] = {u[1], u[3], u[5], u[7]};
+        butterfly<4>(e, tw, n);
+        butterfly<4>(o, tw, n);
+        constexpr float h = 0.70710678118654752440f;
+        const float2 t0 = o[0];
+        const float2 t1 = mk2((o[1].x + o[1].y) * h, (o[1].y - o[1].x) * h);      // * (1 - i) / sqrt 2
+        const float2 t2 = mk2(o[2].y, -o[2].x);                                   // * -i
+        const float2 t3 = mk2((o[3].y - o[3].x) * h, -(o[3].x + o[3].y) * h);     // * (-1 - i) / sqrt 2
+        const float2 t[4] = {t0, t1, t2, t3};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            u[k] = mk2(e[k].x + t[k].x, e[k].y + t[k].y);
+            u[k + 4] = mk2(e[k].x - t[k].x, e[k].y - t[k].y);
+        }
+    } else if constexpr (R == 6 || R == 10) {
+        // DFT-2P (P = 3, 5) = two DFT-P (even / odd inputs) + constant twiddles: X[k] = E[k mod P] + w_2P^k O[k mod P]
+        constexpr int P = R / 2;
+        float2 e[P], o[P];
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            e[i] = u[2 * i];
+            o[i] = u[2 * i + 1];
+        }
+        butterfly<P>(e, tw, n);
+        butterfly<P>(o, tw, n);
+        // w_2P^k = (cos, -sin)(2 pi k / 2P), k < P (the other half is its negative)
+        constexpr float c6[3] = {1.f, 0.5f, -0.5f}, s6[3] = {0.f, 0.86602540378443864676f, 0.86602540378443864676f};
+        constexpr float c10[5] = {1.f, 0.80901699437494742410f, 0.30901699437494742410f, -0.30901699437494742410f, -0.80901699437494742410f};
+        constexpr float s10[5] = {0.f, 0.58778525229247312917f, 0.95105651629515357212f, 0.95105651629515357212f, 0.58778525229247312917f};
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            const float wr = P == 3 ? c6[k] : c10[k], wi = -(P == 3 ? s6[k] : s10[k]);
+            const float2 t = mk2(o[k].x * wr - o[k].y * wi, o[k].x * wi + o[k].y * wr);
+            // X[k] = E[k] + t, X[k + P] = E[k] - t   (w_2P^(k+P) = -w_2P^k; (k + P) mod P = k)
+            u[k] = mk2(e[k].x + t.x, e[k].y + t.y);
+            u[k + P] = mk2(e[k].x - t.x, e[k].y - t.y);
+        }
     } else if constexpr (R == 16) {
         // DFT-16 as 4 x 4 (round 3): r = r0 + 4 r1, q = q1 + 4 q0,
         //     X[q1 + 4 q0] = sum_r0 w4^(q0 r0) [ w16^(q1 r0) sum_r1 w4^(q1 r1) x[r0 + 4 r1] ]
@@ -473,6 +512,9 @@ __global__ __launch_bounds__(NT) GSDR_NO_PK void pfb_lds_kernel(const PfbLdsArgs
             case 11: lds_stage<11>(src, dst, n, p, st, stw, mt, mp, tw, FR, tid, NT); break;
             case 13: lds_stage<13>(src, dst, n, p, st, stw, mt, mp, tw, FR, tid, NT); break;
             case 16: lds_stage<16>(src, dst, n, p, st, stw, mt, mp, tw, FR, tid, NT); break;
+            case 8: lds_stage<8>(src, dst, n, p, st, stw, mt, mp, tw, FR, tid, NT); break;
+            case 6: lds_stage<6>(src, dst, n, p, st, stw, mt, mp, tw, FR, tid, NT); break;
+            case 10: lds_stage<10>(src, dst, n, p, st, stw, mt, mp, tw, FR, tid, NT); break;
             default:
                 if (s == 0)
                     lds_stage_prime_first(R, src, dst, n, roots, st, mt, a.mag_t4, FR, tid, NT);
@@ -550,6 +592,7 @@ struct PfbCuArgs {
     int stage_t[16], stage_tws[16];
     int b_off, b_len;          // second buffer: offset and length (float2), also holds the raw samples first
     int twl;                   // the twiddle table goes into the LDS too
+    int col;                   // the filter works column-wise (see the kernel)
 };
 
 // the prime-first stage with one (q, column) pair per work item; see lds_stage_prime_first
@@ -819,11 +862,10 @@ __device__ __forceinline__ void lds_stage_prime_first_mfma32(int R, const float2
 //  picked by a comparison loses its address space and every ds_read behind it turns into a flat_load)
 __device__ __forceinline__ int pfb_cu_stages(const PfbCuArgs &a, float2 *lds, int src_off, int dst_off, const float2 *tw,
                                              const float2 *roots, int st_radix, int st_mag_t, int st_mag_p,
-                                             int st_t, int st_tws, int tid) {
+                                             int st_t, int st_tws, int tid, int s0, int s1, int &p) {
     constexpr int NT = kPfbCuThreads;
     const int len = a.len, FR = a.G;
-    int p = 1;
-    for (int s = 0; s < a.n_radices; ++s) {
+    for (int s = s0; s < s1; ++s) {
         float2 *src = lds + src_off, *dst = lds + dst_off;
         const int R = __builtin_amdgcn_readlane(st_radix, s);
         const unsigned mt = (unsigned)__builtin_amdgcn_readlane(st_mag_t, s), mp = (unsigned)__builtin_amdgcn_readlane(st_mag_p, s);
@@ -837,6 +879,9 @@ __device__ __forceinline__ int pfb_cu_stages(const PfbCuArgs &a, float2 *lds, in
             case 11: lds_stage<11>(src, dst, len, p, st, stw, mt, mp, tw, FR, tid, NT); break;
             case 13: lds_stage<13>(src, dst, len, p, st, stw, mt, mp, tw, FR, tid, NT); break;
             case 16: lds_stage<16>(src, dst, len, p, st, stw, mt, mp, tw, FR, tid, NT); break;
+            case 8: lds_stage<8>(src, dst, len, p, st, stw, mt, mp, tw, FR, tid, NT); break;
+            case 6: lds_stage<6>(src, dst, len, p, st, stw, mt, mp, tw, FR, tid, NT); break;
+            case 10: lds_stage<10>(src, dst, len, p, st, stw, mt, mp, tw, FR, tid, NT); break;
             default:
                 if (s == 0 && FR * st >= 64)            // many columns: fat tiles, a point per column
                     lds_stage_prime_first_mfma32(R, src, dst, len, roots, st, mt, FR, tid, NT);
@@ -888,14 +933,18 @@ __global__ __launch_bounds__(kPfbCuThreads) GSDR_NO_PK void pfb_cu_kernel(const 
     const int R0 = a.n_radices > 0 && a.radices[0] > 13 ? a.radices[0] : 0;
 
     // ---- 1. loads: the window taps of this thread's points, then the raw samples of the run ----
+    // F == 4 (the client's default): a thread filters COLUMNS k = tid + NT c of all G frames -- consecutive frames
+    // share F - 1 of their F blocks, so a column costs G + 3 LDS reads and four taps instead of 4 G and 4 G -- and
+    // the taps below are those of its columns.  Other F: a thread filters points p = tid + NT c = (frame, k).
+    const bool col_mode = a.col != 0;
     int pk[kPfbCuPts], pfr[kPfbCuPts];
     float wv[kPfbCuPts][4];
     const int npts = G * n;
 #pragma unroll
     for (int c = 0; c < kPfbCuPts; ++c) {
         const int p = tid + NT * c, pc = p < npts ? p : 0;
-        pfr[c] = fdiv(pc, a.mag_n);
-        pk[c] = pc - pfr[c] * n;
+        pfr[c] = col_mode ? 0 : fdiv(pc, a.mag_n);
+        pk[c] = col_mode ? (p < n ? p : 0) : pc - pfr[c] * n;
 #pragma unroll
         for (int j = 0; j < 4; ++j) wv[c][j] = a.window[(unsigned)((j < a.F ? j : a.F - 1) * n + pk[c])];
     }
@@ -922,10 +971,61 @@ __global__ __launch_bounds__(kPfbCuThreads) GSDR_NO_PK void pfb_cu_kernel(const 
     if (TWL)
         for (int k = tid; k < len; k += NT) twl[k] = a.tw[k];
     for (int m = tid; m < R0; m += NT) roots[m] = a.tw[m * (len / R0)];
+    // the bin of every output column, read behind the last stage: out of the LDS (64 clocks), not out of the L2
+    int *sel_l = reinterpret_cast<int *>(twl + (TWL ? len : 0));
+    if (a.sel)
+        for (int u = tid; u < a.n_out; u += NT) sel_l[u] = a.sel[u];
     __syncthreads();
     fft_stamp(1);
 
     // ---- 2. polyphase filter out of the LDS (float accumulate in tap order) ----
+    if (col_mode) {
+        // the frame loop is the outer one so that every register array keeps compile-time indices
+        float2 x0[kPfbCuPts], x1[kPfbCuPts], x2[kPfbCuPts], chv[kPfbCuPts];
+#pragma unroll
+        for (int c = 0; c < kPfbCuPts; ++c) {
+            const int k = tid + NT * c;
+            x0[c] = x1[c] = x2[c] = mk2(0.f, 0.f);
+            chv[c] = mk2(1.f, 0.f);
+            if (k < n) {
+                x0[c] = raw[k];
+                x1[c] = raw[n + k];
+                x2[c] = raw[2 * n + k];
+                if (a.chirp) {
+                    const float2 cc = a.chirp[k];
+                    chv[c] = mk2(cc.x, -cc.y);
+                }
+            }
+        }
+        for (int fr = 0; fr < G; ++fr) {
+            const bool live = fr < Gw;
+            const float2 *rp = raw + (fr + 3) * n;
+            float2 *ap = A + fr * len;
+#pragma unroll
+            for (int c = 0; c < kPfbCuPts; ++c) {
+                const int k = tid + NT * c;
+                if (k < n) {
+                    float2 acc = mk2(0.f, 0.f);
+                    if (live) {
+                        const float2 x3 = rp[k];
+                        acc.x += x0[c].x * wv[c][0];
+                        acc.y += x0[c].y * wv[c][0];
+                        acc.x += x1[c].x * wv[c][1];
+                        acc.y += x1[c].y * wv[c][1];
+                        acc.x += x2[c].x * wv[c][2];
+                        acc.y += x2[c].y * wv[c][2];
+                        acc.x += x3.x * wv[c][3];
+                        acc.y += x3.y * wv[c][3];
+                        x0[c] = x1[c];
+                        x1[c] = x2[c];
+                        x2[c] = x3;
+                        if (a.chirp) acc = cmul(acc, chv[c]);
+                    }
+                    ap[k] = acc;
+                }
+            }
+        }
+    } else {
 #pragma unroll
     for (int c = 0; c < kPfbCuPts; ++c) {
         const int p = tid + NT * c;
@@ -954,6 +1054,7 @@ __global__ __launch_bounds__(kPfbCuThreads) GSDR_NO_PK void pfb_cu_kernel(const 
             A[pfr[c] * len + pk[c]] = acc;
         }
     }
+    }
     if (len > n) {                                          // Bluestein: zero padding up to m
         const int pad = len - n;
         for (int g = tid; g < G * pad; g += NT) {
@@ -966,7 +1067,10 @@ __global__ __launch_bounds__(kPfbCuThreads) GSDR_NO_PK void pfb_cu_kernel(const 
 
     // ---- 3. the transform of all G frames, stage by stage ----
     const float2 *tw = TWL ? twl : a.tw;
-    int res_off = pfb_cu_stages(a, pfb_lds, 0, a.b_off, tw, roots, st_radix, st_mag_t, st_mag_p, st_t, st_tws, tid);
+    int pp = 1;
+    int res_off = pfb_cu_stages(a, pfb_lds, 0, a.b_off, tw, roots, st_radix, st_mag_t, st_mag_p, st_t, st_tws, tid, 0, 1, pp);
+    res_off = pfb_cu_stages(a, pfb_lds, res_off, res_off == 0 ? a.b_off : 0, tw, roots, st_radix, st_mag_t, st_mag_p, st_t,
+                            st_tws, tid, 1, a.n_radices, pp);
     if (a.chirp) {
         // d = conj(A * Bhat); the inverse transform is then a forward one (IFFT(z) = conj(FFT(conj z)) / m)
         float2 *res = pfb_lds + res_off;
@@ -976,28 +1080,31 @@ __global__ __launch_bounds__(kPfbCuThreads) GSDR_NO_PK void pfb_cu_kernel(const 
             res[g] = mk2(v.x, -v.y);
         }
         __syncthreads();
+        pp = 1;
         res_off = pfb_cu_stages(a, pfb_lds, res_off, res_off == 0 ? a.b_off : 0, tw, roots, st_radix, st_mag_t, st_mag_p,
-                                st_t, st_tws, tid);
+                                st_t, st_tws, tid, 0, a.n_radices, pp);
     }
     const float2 *res = pfb_lds + res_off;
     fft_stamp(5);
 
     // ---- 4. bin selection and output ----
     const float inv_m = 1.f / (float)len;
-    for (int g = tid; g < G * a.n_out; g += NT) {
-        const int fr = fdiv(g, a.mag_nout), u = g - fr * a.n_out;
-        if (fr < Gw) {
-            const int bin = a.sel ? a.sel[u] : u;
-            float2 v = res[fr * len + bin];
-            if (a.chirp) {
-                // X[k] = conj(chirp[k]) * conj(e[k]) / m
-                const float2 ch = a.chirp[bin];
-                const float2 r = cmul(mk2(ch.x, -ch.y), mk2(v.x, -v.y));
-                v = mk2(r.x * inv_m, r.y * inv_m);
-            }
-            a.out[(size_t)(f0 + fr) * a.n_out + u] = v;
-        }
+#define GSDR_PFB_CU_EMIT(g, bin_expr)                                                         \
+    {                                                                                         \
+        const int fr = fdiv((g), a.mag_nout), u = (g)-fr * a.n_out;                           \
+        if (fr < Gw) {                                                                        \
+            const int bin = (bin_expr);                                                       \
+            float2 v = res[fr * len + bin];                                                   \
+            if (a.chirp) { /* X[k] = conj(chirp[k]) * conj(e[k]) / m */                       \
+                const float2 ch = a.chirp[bin];                                               \
+                const float2 r = cmul(mk2(ch.x, -ch.y), mk2(v.x, -v.y));                      \
+                v = mk2(r.x * inv_m, r.y * inv_m);                                            \
+            }                                                                                 \
+            a.out[(size_t)(f0 + fr) * a.n_out + u] = v;                                       \
+        }                                                                                     \
     }
+    for (int g = tid; g < G * a.n_out; g += NT) GSDR_PFB_CU_EMIT(g, a.sel ? sel_l[u] : u)
+#undef GSDR_PFB_CU_EMIT
     fft_stamp(7);
 }
 
@@ -1022,6 +1129,9 @@ hipError_t launch_radix(int R, const float2 *x, float2 *y, int n, int p, const f
         case 11: return launch_pass<11>(x, y, n, p, tw, batch, st);
         case 13: return launch_pass<13>(x, y, n, p, tw, batch, st);
         case 16: return launch_pass<16>(x, y, n, p, tw, batch, st);
+        case 8: return launch_pass<8>(x, y, n, p, tw, batch, st);
+        case 6: return launch_pass<6>(x, y, n, p, tw, batch, st);
+        case 10: return launch_pass<10>(x, y, n, p, tw, batch, st);
         default: return hipErrorInvalidValue;
     }
 }
@@ -1238,13 +1348,22 @@ int pfb_lds_plan(int n, int *radices) {
     if (m != 1) return -1;
     for (int i = nbig - 1; i >= 0; --i) push(big[i]);
     m = small;
-    // (round 3) two radix-4 levels per LDS round trip for frames of 4096 points and more: 4096 points 14.8 -> 13.3 us
-    // per buffer, 8192 27.0 -> 23.2.  A radix-16 butterfly keeps one thread in sixteen points busy: below 4096
-    // points too few waves are left to hide each other's latencies (1024 points: two radix-16 stages take the
-    // 4.8 us four radix-4 stages took, profiles/r03_stamp_pfb_cu.log; 64 points 10.0 -> 10.5 us)
+    // (round 3) Fewer, fatter stages -- every stage is a barrier, an LDS round trip and ~60 instructions of index
+    // arithmetic per butterfly whatever its radix:
+    //   * 16 (two radix-4 levels in registers) for frames of 4096 points and more: 4096 points 14.8 -> 13.3 us per
+    //     buffer, 8192 27.0 -> 23.2.  Below that it does not pay: one thread in sixteen points busy leaves too few
+    //     waves to hide each other's latencies (1024 points: two radix-16 stages take what four radix-4 stages took);
+    //   * 8 (= 4 x 2) otherwise: one thread in eight points keeps half of the threads busy;
+    //   * a single 2 left over joins a 3 or a 5: radix 6 / 10 (1230 = 41 * 6 * 5, 1000 = 8 * 5 * 5 * 5).
+    // GSDR_PFB_RADIX8=0: 4s and 2s as in round 2 (A/B runs)
+    static const bool fat = [] { const char *e = std::getenv("GSDR_PFB_RADIX8"); return !(e && e[0] == '0'); }();
     if (n >= 4096)
         while (m % 16 == 0) { push(16); m /= 16; }
+    if (fat)
+        while (m % 8 == 0) { push(8); m /= 8; }
     while (m % 4 == 0) { push(4); m /= 4; }
+    if (fat && m % 2 == 0 && m % 3 == 0) { push(6); m /= 6; }
+    if (fat && m % 2 == 0 && m % 5 == 0) { push(10); m /= 10; }
     for (int q : {2, 3, 5, 7, 11, 13})
         while (m % q == 0) { push(q); m /= q; }
     return cnt <= 16 ? cnt : -1;
@@ -1261,7 +1380,8 @@ static bool pfb_cu_shape(int nfft, int avg, int len, int want, int &G, int &b_of
         if (bl < (long long)G * len) bl = (long long)G * len;
         bl = (bl + 1) & ~1LL;
         for (twl = len <= kPfbLdsTwMaxN ? 1 : 0; twl >= 0; --twl) {
-            const long long total = (al + bl + kPfbLdsMaxPrime + 1 + (twl ? len : 0)) * (long long)sizeof(float2);
+            // + the bin table (n_out <= nfft ints)
+            const long long total = (al + bl + kPfbLdsMaxPrime + 1 + (twl ? len : 0) + (nfft + 1) / 2) * (long long)sizeof(float2);
             if (total <= kPfbCuMaxBytes) {
                 b_off = (int)al;
                 b_len = (int)bl;
@@ -1306,12 +1426,18 @@ static hipError_t launch_pfb_cu(const float2 *carry, int new_0, const float2 *in
     // one workgroup per compute unit: G consecutive frames each (frames_n == 0: a launch that only copies the carry)
     int want = frames_n > 0 ? (frames_n + cus - 1) / cus : 1;
     size_t lds = 0;
+    if (n_out > nfft) return hipSuccess;                  // the bin table in the LDS is sized for n_out <= nfft
     if (!pfb_cu_shape(nfft, avg, len, want, a.G, a.b_off, a.b_len, a.twl, lds)) return hipSuccess;    // does not fit: the caller's other kernel
     a.carry = carry; a.in = in; a.window = window; a.tw = tw; a.sel = sel; a.out = out; a.carry_out = carry_out;
     a.chirp = blue ? blue->d_chirp : nullptr;
     a.bhat = blue ? blue->d_bhat : nullptr;
     a.n = nfft; a.F = avg; a.frames_n = frames_n; a.n_out = n_out; a.new_0 = new_0; a.len = len;
     a.spare_begin = spare_begin; a.spare_n = spare_n;
+    {
+        // column-wise filter: four taps, and enough columns for every thread (GSDR_PFB_COL=0/1: A/B runs)
+        static const int col_env = [] { const char *e = std::getenv("GSDR_PFB_COL"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+        a.col = avg == 4 && (col_env < 0 ? nfft >= kPfbCuThreads / 2 : col_env == 1);
+    }
     a.main_blocks = (unsigned)((frames_n + a.G - 1) / a.G);
     auto magic = [](long long d) { return d <= 1 ? 0u : (unsigned)(0x100000000ULL / (unsigned long long)d + 1ULL); };
     a.mag_n = magic(nfft);
@@ -1370,7 +1496,7 @@ hipError_t launch_pfb_lds(const float2 *carry, int new_0, const float2 *in, cons
     if (cu_mode < 0 && !blue) {
         int r[16];
         const int nr = pfb_lds_plan(nfft, r);
-        for (int i = 0; i < nr; ++i) cu_wanted |= (r[i] != 4 && r[i] != 2 && r[i] != 16);
+        for (int i = 0; i < nr; ++i) cu_wanted |= (r[i] != 4 && r[i] != 2 && r[i] != 16 && r[i] != 8);
     }
     if (cu_wanted) {
         bool taken = false;
@@ -1453,7 +1579,7 @@ bool pfb_cu_takes(int nfft, int avg, int len, bool bluestein) {
         const int nr = pfb_lds_plan(nfft, r);
         if (cu_mode == 0 || nr < 0) return false;
         bool wanted = cu_mode == 1;
-        for (int i = 0; i < nr; ++i) wanted |= (r[i] != 4 && r[i] != 2 && r[i] != 16);
+        for (int i = 0; i < nr; ++i) wanted |= (r[i] != 4 && r[i] != 2 && r[i] != 16 && r[i] != 8);
         if (!wanted) return false;
     }
     return pfb_cu_fits(nfft, avg, len);

@@ -328,20 +328,20 @@ def test_assembly_kernels_keep_two_waves_per_simd(gsdr_lib, tmp_path):
 
 def test_pfb_lds_stage_plan(gsdr_lib):
     """gsdr_pfb_lds_stages: the radices of the in-LDS transform multiply to the frame length, prime
-    factors above 13 come first (the largest in front: its stage needs no twiddles), then 16s, 4s, 2, and the
-    small odd primes; lengths above 8192 points or with a prime factor above 127 are refused (they take
+    factors above 13 come first (the largest in front: its stage needs no twiddles), then 16s (long frames), 8s, 4, 6 / 10 (a 2 joined
+    with a 3 / 5), 2, and the small odd primes; lengths above 8192 points or with a prime factor above 127 are refused (they take
     the other paths)."""
     def stages(n):
         r = (C.c_int * 16)()
         k = gsdr_lib.gsdr_pfb_lds_stages(n, r)
         return None if k < 0 else [r[i] for i in range(k)]
     assert stages(1) == []
-    assert stages(1024) == [4] * 5
-    assert stages(2048) == [4] * 5 + [2]
+    assert stages(1024) == [8, 8, 8, 2]          # (round 3) 8 = 4 x 2 in registers: four stages instead of five
+    assert stages(2048) == [8, 8, 8, 4]
     assert stages(4096) == [16, 16, 16]          # (round 3) two radix-4 levels per LDS round trip from 4096 points on
-    assert stages(1230) == [41, 2, 3, 5]
+    assert stages(1230) == [41, 6, 5]            # the single 2 joins the 3
     assert stages(17 * 19 * 4) == [19, 17, 4]
-    assert stages(127 * 8) == [127, 4, 2]
+    assert stages(127 * 8) == [127, 8]
     assert stages(8192) == [16, 16, 16, 2]
     assert stages(131 * 4) is None and stages(8193) is None and stages(16384) is None and stages(0) is None
     assert stages(4099) is None                      # prime above 127
@@ -358,4 +358,4 @@ def test_pfb_lds_stage_plan(gsdr_lib):
         assert int(np.prod(st, dtype=np.int64)) == n if st else n == 1
         big = [r for r in st if r > 13]
         assert st[:len(big)] == sorted(big, reverse=True)
-        assert all(r in (2, 3, 4, 5, 7, 11, 13, 16) for r in st[len(big):])
+        assert all(r in (2, 3, 4, 5, 6, 7, 8, 10, 11, 13, 16) for r in st[len(big):])
