@@ -7,7 +7,7 @@ import gpu_sdr_amd as g
 from gpu_sdr_amd import _lib
 dbg = C.CDLL(_lib.LIB_PATH)
 dev = torch.device("cuda:0")
-L, rate = 1_000_000, 200_000_000
+L, rate = int(os.environ.get("STAMP_L", "1000000")), 200_000_000
 nfft = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 N = min(1024, nfft)
 rng = np.random.default_rng(nfft)
@@ -22,6 +22,8 @@ torch.cuda.synchronize()
 stamps = torch.zeros(8 * 20000, dtype=torch.int64, device=dev)
 dbg.gsdr_debug_set_fft_stamp_buffer.argtypes = [C.c_void_p]
 assert dbg.gsdr_debug_set_fft_stamp_buffer(C.c_void_p(stamps.data_ptr())) == 0
+if os.environ.get("STAMP_MASK"):
+    assert dbg.gsdr_debug_set_fft_stamp_mask(C.c_uint(int(os.environ["STAMP_MASK"], 0))) == 0
 for rep in range(3):
     stamps.zero_()
     torch.cuda.synchronize()
@@ -35,6 +37,9 @@ for rep in range(3):
     d = dict(nfft=nfft, wgs=len(s), start_spread_us=round(float(t[:, 0].max() - base), 2), last_end_us=round(float(t[:, 7].max() - base), 2),
              mean_life_us=round(float((t[:, 7] - t[:, 0]).mean()), 2),
              filter_us=round(float((t[:, 1] - t[:, 0]).mean()), 2))
+    if s[:, 6].max() > 0 and nfft in (256, 1024, 2048):      # slot 6: core clocks over the workgroup's life (lds kernel, <= 4 stages)
+        d["core_clock_ghz"] = round(float((s[:, 6] / ((s[:, 7] - s[:, 0]) * 10.0)).mean()), 3)
+        s[:, 6] = 0
     prev = 1
     for sl in range(2, 7):
         if s[:, sl].max() > 0:

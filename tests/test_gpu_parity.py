@@ -768,6 +768,12 @@ NOISE_FFT_CASES = [
     (3 * 1009, 2, 40_000, 3),                  # 3027 -> 8192: the longest Bluestein length the LDS takes
     (2048, 4, 100_000, 2),                     # two frames per compute unit at most: the run kernel's LDS limit
     (4096, 4, 100_000, 2),                     # a frame does not fit the run kernel: the frame-per-workgroup kernel
+    (250, 4, 20_000, 3),                       # 10 5 5: the radix-10 butterfly (a 2 joined with a 5)
+    (70, 3, 5_000, 3),                         # 7 10
+    (600, 4, 30_000, 3),                       # 8 5 5 3; column-wise filter (four taps, >= 512 columns)
+    (1536, 4, 60_000, 2),                      # 8 8 8 3
+    (1230, 3, 60_000, 3),                      # 41 6 5 with three taps: the run kernel's point-wise filter
+    (1000, 5, 50_000, 3),                      # five taps: the fifth is read inside the filter loop
 ]
 
 
@@ -821,7 +827,7 @@ def pfb_lds_fits(nfft, avg=4):
     while mm < 2 * nfft - 1:
         mm *= 2
     even = lambda v: (v + 1) & ~1
-    return mm <= 8192 and (even(mm) + even(max(mm, avg * nfft)) + 128) * 8 <= 156 * 1024
+    return mm <= 8192 and (even(mm) + even(max(mm, avg * nfft)) + 128 + (nfft + 1) // 2) * 8 <= 156 * 1024
 
 
 @pytest.mark.parametrize("path", ["lds", "global"])
