@@ -253,7 +253,7 @@ __device__ __forceinline__ void fft_stamp(int slot) {
     if (g_fft_stamp_buf && threadIdx.x == 0 && (g_fft_stamp_mask >> slot & 1u))
         g_fft_stamp_buf[8 * (size_t)blockIdx.x + slot] = __builtin_amdgcn_s_memrealtime();
 }
-// core clocks between two points (s_memtime counts shader clocks): stamp_core(slot, 0) remembers, (slot, 1) stores the difference
+// core clocks between two points (s_memtime counts shader clocks): (slot, c0, 0) remembers, (slot, c0, 1) stores the difference
 __device__ __forceinline__ void fft_stamp_core(int slot, unsigned long long &c0, int end) {
     if (!end) c0 = __builtin_amdgcn_s_memtime();
     else if (g_fft_stamp_buf && threadIdx.x == 0) g_fft_stamp_buf[8 * (size_t)blockIdx.x + slot] = __builtin_amdgcn_s_memtime() - c0;
@@ -297,26 +297,23 @@ __device__ __forceinline__ float2 pfb_window_at(const PfbLdsArgs &a, int q) {
 template <int R>
 __device__ __forceinline__ void lds_stage(const float2 *src, float2 *dst, int n, int p, int t, int tws, unsigned mag_t,
                                           unsigned mag_p, const float2 *__restrict__ tw, int FR, int tid, int NT) {
-    // every product below is of two numbers under 2^17 and stays under 2^24: the 24-bit multiply runs at full rate,
-    // v_mul_lo_u32 at a quarter (a radix-8 butterfly had eighteen of them in its addresses)
     for (int g = tid; g < FR * t; g += NT) {
-        const int fr = FR == 1 ? 0 : fdiv(g, mag_t), i = g - __mul24(fr, t);
-        const int k = i - __mul24(fdiv(i, mag_p), p);
+        const int fr = FR == 1 ? 0 : fdiv(g, mag_t), i = g - fr * t;
+        const int k = i - fdiv(i, mag_p) * p;
         const int j = (i - k) * R + k;
-        const int frn = __mul24(fr, n);
-        const float2 *xb = src + (frn + i);       // + r t: a scalar offset per r
-        float2 *yb = dst + (frn + j);             // + r p: likewise
+        const float2 *xb = src + fr * n;
+        float2 *yb = dst + fr * n;
         float2 u[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) u[r] = xb[r * t];
+        for (int r = 0; r < R; ++r) u[r] = xb[i + r * t];
         if (p != 1) {                             // the first stage has no twiddles in front (k == 0)
-            const int kt = __mul24(k, tws);
+            const int kt = k * tws;
 #pragma unroll
             for (int r = 1; r < R; ++r) u[r] = cmul(u[r], tw[r * kt]);
         }
         butterfly<R>(u, tw, n);
 #pragma unroll
-        for (int r = 0; r < R; ++r) yb[r * p] = u[r];
+        for (int r = 0; r < R; ++r) yb[j + r * p] = u[r];
     }
 }
 
@@ -451,7 +448,7 @@ __global__ __launch_bounds__(NT) GSDR_NO_PK void pfb_lds_kernel(const PfbLdsArgs
     for (int c = 0; c < 4; ++c) {
         const int idx = tid + NT * c;
         const int fr = FR == 1 ? 0 : fdiv(idx, a.mag_nout);
-        const int u = idx - __mul24(fr, a.n_out);
+        const int u = idx - fr * a.n_out;
         sel0[c] = a.sel && idx < FR * a.n_out ? a.sel[u] : u;
     }
     bool first = true;
@@ -466,9 +463,9 @@ __global__ __launch_bounds__(NT) GSDR_NO_PK void pfb_lds_kernel(const PfbLdsArgs
             const int idx = base + NT * c;
             const int idc = idx < FR * n ? idx : FR * n - 1;
             const int fr = FR == 1 ? 0 : fdiv(idc, a.mag_n);
-            kk[c] = idc - __mul24(fr, n);
+            kk[c] = idc - fr * n;
             ok[c] = idx < FR * n && f0 + fr < a.frames_n;
-            q0[c] = ok[c] ? f0 * n + __mul24(fr, n) + kk[c] : a.new_0; // W[new_0] = in[0] is always there
+            q0[c] = ok[c] ? (f0 + fr) * n + kk[c] : a.new_0; // W[new_0] = in[0] is always there
             acc[c] = mk2(0.f, 0.f);
         }
         for (int i0 = 0; i0 < a.F; i0 += 4) {
@@ -542,17 +539,16 @@ __global__ __launch_bounds__(NT) GSDR_NO_PK void pfb_lds_kernel(const PfbLdsArgs
         src = dst;
         dst = t2;
     }
-    float2 *out0 = a.out + (size_t)f0 * a.n_out;          // the first frame of this workgroup: a scalar base
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int idx = tid + NT * c;
-        const int fr = FR == 1 ? 0 : fdiv(idx, a.mag_nout), u = idx - __mul24(fr, a.n_out);
-        if (idx < FR * a.n_out && f0 + fr < a.frames_n) out0[__mul24(fr, a.n_out) + u] = src[__mul24(fr, n) + sel0[c]];
+        const int fr = FR == 1 ? 0 : fdiv(idx, a.mag_nout), u = idx - fr * a.n_out;
+        if (idx < FR * a.n_out && f0 + fr < a.frames_n) a.out[(size_t)(f0 + fr) * a.n_out + u] = src[fr * n + sel0[c]];
     }
     for (int idx = tid + 4 * NT; idx < FR * a.n_out; idx += NT) {
-        const int fr = FR == 1 ? 0 : fdiv(idx, a.mag_nout), u = idx - __mul24(fr, a.n_out);
+        const int fr = FR == 1 ? 0 : fdiv(idx, a.mag_nout), u = idx - fr * a.n_out;
         const int r = f0 + fr;
-        if (r < a.frames_n) out0[__mul24(fr, a.n_out) + u] = src[__mul24(fr, n) + (a.sel ? a.sel[u] : u)];
+        if (r < a.frames_n) a.out[(size_t)r * a.n_out + u] = src[fr * n + (a.sel ? a.sel[u] : u)];
     }
     fft_stamp_core(6, core0, 1);
     fft_stamp(7);
@@ -690,8 +686,8 @@ __device__ __forceinline__ void lds_stage_prime_first_mfma(int R, const float2 *
         const bool col_ok = c < NC;
         c = col_ok ? c : NC - 1;
         const int part = c & 1, ci = c >> 1;
-        const int fr = FR == 1 ? 0 : fdiv(ci, mag_t), i = ci - __mul24(fr, t);
-        const int col0 = 2 * (__mul24(fr, n) + i) + part;               // float index of x_0's component
+        const int fr = FR == 1 ? 0 : fdiv(ci, mag_t), i = ci - fr * t;
+        const int col0 = 2 * (fr * n + i) + part;               // float index of x_0's component
         int idx = qc * (1 + l4);                                // <= 4 h < 2 R
         idx = idx >= R ? idx - R : idx;
         int dq = 4 * qc;
@@ -756,7 +752,7 @@ __device__ __forceinline__ void lds_stage_prime_first_mfma(int R, const float2 *
         // The re and im columns of a point sit in neighbouring lanes: the cross terms are one DPP swap away.
         const float x0p = sf[col0];
         const float sgn = part ? -1.f : 1.f;
-        const int obase = 2 * (__mul24(fr, n) + __mul24(i, R)) + part;
+        const int obase = 2 * (fr * n + i * R) + part;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int qq = mt * 16 + 4 * l4 + j;
@@ -795,8 +791,8 @@ __device__ __forceinline__ void lds_stage_prime_first_mfma32(int R, const float2
         int c = nt * 32 + l32;
         const bool col_ok = c < NC;
         c = col_ok ? c : NC - 1;
-        const int fr = FR == 1 ? 0 : fdiv(c, mag_t), i = c - __mul24(fr, t);
-        const float2 *xc = src + __mul24(fr, n) + i;                    // x_r of this column: xc[r * t]
+        const int fr = FR == 1 ? 0 : fdiv(c, mag_t), i = c - fr * t;
+        const float2 *xc = src + fr * n + i;                    // x_r of this column: xc[r * t]
         int idx = qc * (1 + l2);
         const int dq = 2 * qc;                                  // < R
         int r = 1 + l2;
@@ -856,8 +852,8 @@ __device__ __forceinline__ void lds_stage_prime_first_mfma32(int R, const float2
         //     out[q] = x_0 + A - iB,   out[R - q] = x_0 + A + iB
         const float2 x0 = xc[0];
         const int qb = mt * 32 + 4 * l2;                        // the lane's rows: qb + 8 (j / 4) + j % 4
-        float2 *oq = dst + __mul24(fr, n) + __mul24(i, R) + qb;                 // out[qb + off]
-        float2 *om = dst + __mul24(fr, n) + __mul24(i, R) + (R - qb);           // out[R - qb - off]
+        float2 *oq = dst + fr * n + i * R + qb;                 // out[qb + off]
+        float2 *om = dst + fr * n + i * R + (R - qb);           // out[R - qb - off]
         const int room = col_ok ? h - qb : -1;                  // rows with off <= room exist
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -959,7 +955,7 @@ __global__ __launch_bounds__(kPfbCuThreads) GSDR_NO_PK void pfb_cu_kernel(const 
     for (int c = 0; c < kPfbCuPts; ++c) {
         const int p = tid + NT * c, pc = p < npts ? p : 0;
         pfr[c] = col_mode ? 0 : fdiv(pc, a.mag_n);
-        pk[c] = col_mode ? (p < n ? p : 0) : pc - __mul24(pfr[c], n);
+        pk[c] = col_mode ? (p < n ? p : 0) : pc - pfr[c] * n;
 #pragma unroll
         for (int j = 0; j < 4; ++j) wv[c][j] = a.window[(unsigned)((j < a.F ? j : a.F - 1) * n + pk[c])];
     }
@@ -1047,7 +1043,7 @@ __global__ __launch_bounds__(kPfbCuThreads) GSDR_NO_PK void pfb_cu_kernel(const 
         if (p < npts) {
             float2 acc = mk2(0.f, 0.f);
             if (pfr[c] < Gw) {
-                const float2 *rp = raw + __mul24(pfr[c], n) + pk[c];
+                const float2 *rp = raw + pfr[c] * n + pk[c];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     if (i < a.F) {
@@ -1066,7 +1062,7 @@ __global__ __launch_bounds__(kPfbCuThreads) GSDR_NO_PK void pfb_cu_kernel(const 
                     acc = cmul(acc, mk2(ch.x, -ch.y));
                 }
             }
-            A[__mul24(pfr[c], len) + pk[c]] = acc;
+            A[pfr[c] * len + pk[c]] = acc;
         }
     }
     }
@@ -1104,19 +1100,18 @@ __global__ __launch_bounds__(kPfbCuThreads) GSDR_NO_PK void pfb_cu_kernel(const 
 
     // ---- 4. bin selection and output ----
     const float inv_m = 1.f / (float)len;
-    float2 *out0 = a.out + (size_t)f0 * a.n_out;          // the first frame of this run: a scalar base
 #define GSDR_PFB_CU_EMIT(g, bin_expr)                                                         \
     {                                                                                         \
-        const int fr = fdiv((g), a.mag_nout), u = (g)-__mul24(fr, a.n_out);                   \
+        const int fr = fdiv((g), a.mag_nout), u = (g)-fr * a.n_out;                           \
         if (fr < Gw) {                                                                        \
             const int bin = (bin_expr);                                                       \
-            float2 v = res[__mul24(fr, len) + bin];                                           \
+            float2 v = res[fr * len + bin];                                                   \
             if (a.chirp) { /* X[k] = conj(chirp[k]) * conj(e[k]) / m */                       \
                 const float2 ch = a.chirp[bin];                                               \
                 const float2 r = cmul(mk2(ch.x, -ch.y), mk2(v.x, -v.y));                      \
                 v = mk2(r.x * inv_m, r.y * inv_m);                                            \
             }                                                                                 \
-            out0[__mul24(fr, a.n_out) + u] = v;                                               \
+            a.out[(size_t)(f0 + fr) * a.n_out + u] = v;                                       \
         }                                                                                     \
     }
     for (int g = tid; g < G * a.n_out; g += NT) GSDR_PFB_CU_EMIT(g, a.sel ? sel_l[u] : u)
@@ -1538,6 +1533,9 @@ hipError_t launch_pfb_lds(const float2 *carry, int new_0, const float2 *in, cons
     a.spare_begin = spare_begin; a.spare_n = spare_n;
     // short frames share a workgroup: at least ~1024 points of work per workgroup
     a.FR = nfft >= 1024 ? 1 : (1024 + nfft - 1) / nfft;
+    static const int fr_env = [] { const char *e = std::getenv("GSDR_PFB_FR"); return e ? std::atoi(e) : 0; }();      // A/B runs
+    static const int wide_env = [] { const char *e = std::getenv("GSDR_PFB_WIDE"); return e ? std::atoi(e) : -1; }();
+    if (fr_env > 0 && (long long)fr_env * nfft <= 4096) a.FR = fr_env;
     if (a.FR > 64) a.FR = 64;
     a.main_blocks = (unsigned)((frames_n + a.FR - 1) / a.FR);
     if (window_len > 0x7fffffffLL - nfft) return hipErrorInvalidValue;     // 32-bit window positions in the kernel
@@ -1568,7 +1566,7 @@ hipError_t launch_pfb_lds(const float2 *carry, int new_0, const float2 *in, cons
     static std::atomic<unsigned long long> attr_done{0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return hipErrorInvalidDevice;
-    const bool wide = nfft >= 2048;                      // 512 threads per frame
+    const bool wide = wide_env >= 0 ? wide_env != 0 : nfft >= 2048;                      // 512 threads per frame
     const void *fn = twl ? (wide ? reinterpret_cast<const void *>(pfb_lds_kernel<true, 512>)
                                  : reinterpret_cast<const void *>(pfb_lds_kernel<true, 256>))
                          : (wide ? reinterpret_cast<const void *>(pfb_lds_kernel<false, 512>)

@@ -6,3 +6,4 @@ python -m pytest tests -m gpu -q > gpurun_out/r03_pytest.log 2>&1; echo "pytest 
 timeout -k 10 600 python bench.py > gpurun_out/r03_bench_default.json 2> gpurun_out/r03_bench_default.err; echo "bench rc=$?"
 timeout -k 10 300 python bench.py --gpus 2 --steps 100 --warmup 10 --no-extras --no-cpu > gpurun_out/r03_n2_one_device.json 2> gpurun_out/r03_n2_one_device.err; echo "n2 rc=$?"
 cut -c1-400 gpurun_out/r03_n2_one_device.json
+python scratch/pfb_sweep.py 64 256 1000 1024 1230 2048 1016 4096 8192 1018 1004 2>&1 | grep TONES | tee gpurun_out/r03_pfb_sweep_final.log
