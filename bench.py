@@ -564,7 +564,8 @@ def measure(engine, key, device, seed, steps, warmup, dist, api, min_seconds, wi
     wl = WORKLOADS[key]
     # chirp: a step is ONE launch of ~4 us; an event pair around it costs ~2.5 us of stream time, so the
     # timed region of `value` carries no events and the event-bracketed durations come from a pass of their own
-    short_step = wl["kind"] == "chirp"
+    # (chirp: 4 - 5 us per launch; TONES / NOISE inside the LDS: one launch of 10 - 15 us per step when run in order)
+    short_step = wl["kind"] == "chirp" or (wl["kind"] == "pfb" and api == "inorder")
     r = time_workload(engine, wl, device, seed, steps, warmup, dist, api=api, min_seconds=min_seconds,
                       profile_every=0 if short_step else None)
     world = dist.get_world_size() if dist is not None else 1
@@ -704,7 +705,9 @@ def main(argv=None, engine=None):
     # where the tensors of barrier()/max_over_ranks() live: on the GPU for RCCL, on the CPU for gloo
     ctl_device = device if (dist is None or backend == "nccl") else None
 
-    api = args.api if args.api != "auto" else ("pipelined" if wl["kind"] in ("direct", "pfb") else "inorder")
+    # the matrix-core DDC overlaps consecutive buffers on rotating streams; TONES / NOISE / chirp launches are 4 - 15 us
+    # and keep one stream (an event between calls costs 2 - 3 us of stream time: profiles/r03_pfb_api_ab.log)
+    api = args.api if args.api != "auto" else ("pipelined" if wl["kind"] == "direct" else "inorder")
 
     m = _measure_with_ctl(engine, args.workload, device, ctl_device, seed, args.steps, args.warmup, dist, api,
                           args.min_seconds)
@@ -755,7 +758,7 @@ def main(argv=None, engine=None):
                 if key == args.workload:
                     continue
                 ek = WORKLOADS[key]
-                eapi = "pipelined" if ek["kind"] in ("direct", "pfb") else "inorder"   # the DDC and the PFB overlap buffers
+                eapi = "pipelined" if ek["kind"] == "direct" else "inorder"   # the DDC overlaps buffers; the others keep one stream
                 e = measure(engine, key, device, seed, steps=500, warmup=50, dist=None, api=eapi, min_seconds=0.5)
                 er = e["r"]
                 extras[key] = dict(workload=ek["name"], msamples_per_s=round(e["value"], 2), api=er["api"],

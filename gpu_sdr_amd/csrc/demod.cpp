@@ -877,33 +877,9 @@ int enqueue_pfb_lds(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t st
     const gsdr::FftPlan *blue = h->pfb_blue ? &h->fft : nullptr;
     const float2 *tw = h->pfb_blue ? h->fft.d_tw : h->d_pfb_tw;
     hipEvent_t stop = nullptr;
-    // (the run-per-compute-unit kernel fills every unit with one workgroup and most of its LDS: two of its launches
-    //  cannot share the chip, so splitting off the carry copy only adds a launch and an event -- 16.4 us per buffer in
-    //  one launch against 17.7 split, profiles/r03_bench_default.json -- and its calls stay whole)
-    const bool split = h->pipe_overlap && !h->pfb_cu;
-    if (h->pipe_overlap && !split) {
-        if (record_begin(h, st, &stop)) return -1;
-        HIPCHK(h, gsdr::launch_pfb_lds(carry, h->bh.new_0, in, h->d_fft_win, tw, h->nfft, h->F, cb,
-                                       sel, h->ddc_channels, out, carry_out, h->bh.spare_begin, spare_n, wlen, st, blue));
-        if (stop) HIPCHK(h, hipEventRecord(stop, st));
-        stop = nullptr;
-        HIPCHK(h, hipEventRecord(h->ev_abs[h->pipe_seq % 4], st));
-    } else if (split) {
-        // overlapped entry: consecutive buffers run on the compute streams in turn.  What ties them
-        // together is the carry alone: a launch of its own copies this call's leftovers first (it needs
-        // the previous call's carry and this buffer, nothing of this call's frames), its event lets the
-        // next call start, and the frames follow -- beside the frames of the neighbouring buffers.
-        HIPCHK(h, gsdr::launch_pfb_lds(carry, h->bh.new_0, in, h->d_fft_win, tw, h->nfft, h->F, 0,
-                                       sel, h->ddc_channels, out, carry_out, h->bh.spare_begin, spare_n, wlen, st, blue));
-        HIPCHK(h, hipEventRecord(h->ev_abs[h->pipe_seq % 4], st));
-        if (record_begin(h, st, &stop)) return -1;
-        HIPCHK(h, gsdr::launch_pfb_lds(carry, h->bh.new_0, in, h->d_fft_win, tw, h->nfft, h->F, cb,
-                                       sel, h->ddc_channels, out, nullptr, 0, 0, wlen, st, blue));
-    } else {
-        if (record_begin(h, st, &stop)) return -1;
-        HIPCHK(h, gsdr::launch_pfb_lds(carry, h->bh.new_0, in, h->d_fft_win, tw, h->nfft, h->F, cb,
-                                       sel, h->ddc_channels, out, carry_out, h->bh.spare_begin, spare_n, wlen, st, blue));
-    }
+    if (record_begin(h, st, &stop)) return -1;
+    HIPCHK(h, gsdr::launch_pfb_lds(carry, h->bh.new_0, in, h->d_fft_win, tw, h->nfft, h->F, cb,
+                                   sel, h->ddc_channels, out, carry_out, h->bh.spare_begin, spare_n, wlen, st, blue));
     if (stop) HIPCHK(h, hipEventRecord(stop, st));
     h->win_seq++;
     const int ret = h->ddc_channels * cb;  // :546 (TONES), copy_size :638 (NOISE)
@@ -1489,7 +1465,11 @@ static int pipeline_init_parts(gsdr_demod *h) {
 static int pipeline_compute(gsdr_demod *h, gsdr_demod::Slot &sl, hipEvent_t up, const float2 *in, float2 *out) {
     const bool ddc = (h->mode == GSDR_DIRECT && h->decim > 0) ||
                      h->mode == GSDR_TONES || h->mode == GSDR_NOISE;
-    const bool overlap = h->pipe_overlap_allowed && (h->mfma || h->pfb_lds) && ddc;
+    // TONES / NOISE inside the LDS keep the one compute stream: a launch is 10 - 15 us, the events that tie the calls
+    // of rotating streams together (carry, completion) cost more than their overlap gives -- per 1 M-sample buffer
+    // 16.3 against 12.0 us in order at 1024 points, 17.0 against 10.2 at 256, 25.7 against 15.4 at 1230
+    // (profiles/r03_pfb_api_ab.log)
+    const bool overlap = h->pipe_overlap_allowed && h->mfma && !h->pfb_lds && ddc;
     hipStream_t cs = overlap ? h->s_main[h->pipe_seq % (unsigned)h->pipe_streams] : h->stream;
     if (up) HIPCHK(h, hipStreamWaitEvent(cs, up, 0));
     if (overlap) {
