@@ -604,6 +604,8 @@ struct PfbCuArgs {
     int b_off, b_len;          // second buffer: offset and length (float2), also holds the raw samples first
     int twl;                   // the twiddle table goes into the LDS too
     int col;                   // the filter works column-wise (see the kernel)
+    int direct;                // ... and straight out of global memory: 1: <1, 11>, 2: <2, 7>, 3: <4, 4> (columns per thread, blocks), 4: <1, 11> in groups
+    int dir_s, dir_gs;         // frames shorter than the workgroup: dir_s groups of threads take dir_gs consecutive frames each
 };
 
 // the prime-first stage with one (q, column) pair per work item; see lds_stage_prime_first
@@ -912,6 +914,70 @@ __device__ __forceinline__ int pfb_cu_stages(const PfbCuArgs &a, float2 *lds, in
     return src_off;
 }
 
+// The polyphase filter of a run straight out of global memory, for four taps: a thread takes CPT columns k = tid + NT c
+// and loads, per column, the NB >= Gw + 3 blocks the run's frames are made of -- ONE load per (block, column) where
+// the frame-per-workgroup kernel issues four (every frame reloads its three shared blocks) and the staged path of this
+// kernel puts a trip through the LDS and a barrier in between -- then forms every frame of the run from registers
+// (float accumulation in tap order, ref cpp/kernels.cu:474-516).  All loads of a thread are in flight together.
+template <int CPT, int NB, bool GROUPS>
+__device__ __forceinline__ void pfb_cu_filter_direct(const PfbCuArgs &a, float2 *A, int f0, int Gw, int tid) {
+    constexpr int NT = kPfbCuThreads;
+    const int n = a.n, len = a.len;
+    // GROUPS (frames of at most half the workgroup): the threads form dir_s groups of n, group g takes the dir_gs
+    // consecutive frames from g * dir_gs on (their dir_gs + 3 blocks); otherwise one group takes the whole run -- a
+    // template parameter, so that without groups every condition on a frame or block number stays wave-uniform
+    const int grp = GROUPS ? fdiv(tid, a.mag_n) : 0;
+    const int k0 = tid - grp * n;
+    const int fa = grp * a.dir_gs;                         // first frame of this thread's group, within the run
+    const int gf = a.G - fa < a.dir_gs ? a.G - fa : a.dir_gs;       // frames of the group (<= 0: none)
+    const int gw = Gw - fa;                                // ... of which exist (may be <= 0)
+    float2 xr[CPT][NB];
+    float w[CPT][4];
+    float2 ch[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+        const int k = k0 + NT * c;
+        const bool live = k < n && grp < a.dir_s && gw > 0;  // (columns beyond the frame, groups without a frame: no loads)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[c][j] = live ? a.window[(unsigned)(j * n + k)] : 0.f;
+        ch[c] = mk2(1.f, 0.f);
+        if (a.chirp && live) {
+            const float2 cc = a.chirp[k];
+            ch[c] = mk2(cc.x, -cc.y);
+        }
+        const int q0 = (f0 + fa) * n + k;                  // window position of block 0 of this column
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            xr[c][b] = mk2(0.f, 0.f);
+            if (live && b < gw + 3) {
+                const int q = q0 + b * n;
+                xr[c][b] = q < a.new_0 ? a.carry[q] : a.in[q - a.new_0];
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+        const int k = k0 + NT * c;
+        if (k < n && grp < a.dir_s) {
+#pragma unroll
+            for (int fr = 0; fr < NB - 3; ++fr) {
+                if (fr < gf) {
+                    float2 acc = mk2(0.f, 0.f);
+                    if (fr < gw) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            acc.x += xr[c][fr + i].x * w[c][i];
+                            acc.y += xr[c][fr + i].y * w[c][i];
+                        }
+                        if (a.chirp) acc = cmul(acc, ch[c]);
+                    }
+                    A[(fa + fr) * len + k] = acc;
+                }
+            }
+        }
+    }
+}
+
 // TWL: the twiddle table is copied into the LDS (a template parameter, not a run-time choice between an LDS and a
 // global pointer: that would be a flat pointer)
 template <bool TWL>
@@ -943,6 +1009,22 @@ __global__ __launch_bounds__(kPfbCuThreads) GSDR_NO_PK void pfb_cu_kernel(const 
     const int st_t = a.stage_t[st_lane], st_tws = a.stage_tws[st_lane];
     const int R0 = a.n_radices > 0 && a.radices[0] > 13 ? a.radices[0] : 0;
 
+    int *sel_l = reinterpret_cast<int *>(twl + (TWL ? len : 0));
+    if (a.direct) {
+        // ---- 1 + 2 in one: tables into the LDS, the filter straight out of global memory (pfb_cu_filter_direct) ----
+        if (TWL)
+            for (int k = tid; k < len; k += NT) twl[k] = a.tw[k];
+        for (int m = tid; m < R0; m += NT) roots[m] = a.tw[m * (len / R0)];
+        if (a.sel)
+            for (int u = tid; u < a.n_out; u += NT) sel_l[u] = a.sel[u];
+        switch (a.direct) {
+            case 1: pfb_cu_filter_direct<1, 11, false>(a, A, f0, Gw, tid); break;
+            case 2: pfb_cu_filter_direct<2, 7, false>(a, A, f0, Gw, tid); break;
+            case 3: pfb_cu_filter_direct<4, 4, false>(a, A, f0, Gw, tid); break;
+            default: pfb_cu_filter_direct<1, 11, true>(a, A, f0, Gw, tid); break;
+        }
+        fft_stamp(1);
+    } else {
     // ---- 1. loads: the window taps of this thread's points, then the raw samples of the run ----
     // F == 4 (the client's default): a thread filters COLUMNS k = tid + NT c of all G frames -- consecutive frames
     // share F - 1 of their F blocks, so a column costs G + 3 LDS reads and four taps instead of 4 G and 4 G -- and
@@ -983,7 +1065,6 @@ __global__ __launch_bounds__(kPfbCuThreads) GSDR_NO_PK void pfb_cu_kernel(const 
         for (int k = tid; k < len; k += NT) twl[k] = a.tw[k];
     for (int m = tid; m < R0; m += NT) roots[m] = a.tw[m * (len / R0)];
     // the bin of every output column, read behind the last stage: out of the LDS (64 clocks), not out of the L2
-    int *sel_l = reinterpret_cast<int *>(twl + (TWL ? len : 0));
     if (a.sel)
         for (int u = tid; u < a.n_out; u += NT) sel_l[u] = a.sel[u];
     __syncthreads();
@@ -1066,6 +1147,7 @@ __global__ __launch_bounds__(kPfbCuThreads) GSDR_NO_PK void pfb_cu_kernel(const 
         }
     }
     }
+    }   // (!a.direct)
     if (len > n) {                                          // Bluestein: zero padding up to m
         const int pad = len - n;
         for (int g = tid; g < G * pad; g += NT) {
@@ -1383,6 +1465,16 @@ int pfb_lds_plan(int n, int *radices) {
     return cnt <= 16 ? cnt : -1;
 }
 
+// Four taps and frames of 128 points and more: the run kernel filters straight out of global memory (one load per
+// block and column instead of four, no trip through the LDS) and is the faster one for powers of two as well --
+// same box, per 1 M-sample buffer: 256 points 10.1 against 10.3 us, 512: 10.2 / 10.8, 1024: 10.7 / 12.2, 2048:
+// 10.4 / 11.9; 16 points 9.9 against 9.4 and 64 points equal: short frames stay a frame set per workgroup
+// (profiles/r03_pfb_ab_direct.log).  GSDR_PFB_DIRECT=0 switches the direct filter off, and this rule with it.
+static bool pfb_cu_direct_pays(int nfft, int avg) {
+    static const int direct_env = [] { const char *e = std::getenv("GSDR_PFB_DIRECT"); return e ? std::atoi(e) : 1; }();
+    return direct_env && avg == 4 && nfft >= 128;
+}
+
 // Shape of the run-per-compute-unit kernel for frames of nfft points transformed at length `len` (nfft, or
 // Bluestein's m): frames per workgroup G (at most `want`), the offset and size of the second LDS buffer, whether
 // the twiddle table fits beside them.  False when not even one frame fits.
@@ -1451,6 +1543,18 @@ static hipError_t launch_pfb_cu(const float2 *carry, int new_0, const float2 *in
         // column-wise filter: four taps, and enough columns for every thread (GSDR_PFB_COL=0/1: A/B runs)
         static const int col_env = [] { const char *e = std::getenv("GSDR_PFB_COL"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
         a.col = avg == 4 && (col_env < 0 ? nfft >= kPfbCuThreads / 2 : col_env == 1);
+        // ... and straight out of global memory when the run's blocks fit the registers (GSDR_PFB_DIRECT=0: staged)
+        static const int direct_env = [] { const char *e = std::getenv("GSDR_PFB_DIRECT"); return e ? std::atoi(e) : 1; }();
+        const int cpt = (nfft + kPfbCuThreads - 1) / kPfbCuThreads;
+        a.dir_s = cpt == 1 ? kPfbCuThreads / nfft : 1;     // groups of threads (frames shorter than the workgroup)
+        a.dir_gs = (a.G + a.dir_s - 1) / a.dir_s;          // frames per group
+        const int nb = a.dir_gs + 3;
+        a.direct = 0;
+        if (avg == 4 && direct_env) {
+            if (cpt == 1 && nb <= 11) a.direct = a.dir_s > 1 ? 4 : 1;
+            else if (cpt <= 2 && nb <= 7) a.direct = 2;
+            else if (cpt <= 4 && nb <= 4) a.direct = 3;
+        }
     }
     a.main_blocks = (unsigned)((frames_n + a.G - 1) / a.G);
     auto magic = [](long long d) { return d <= 1 ? 0u : (unsigned)(0x100000000ULL / (unsigned long long)d + 1ULL); };
@@ -1511,6 +1615,7 @@ hipError_t launch_pfb_lds(const float2 *carry, int new_0, const float2 *in, cons
         int r[16];
         const int nr = pfb_lds_plan(nfft, r);
         for (int i = 0; i < nr; ++i) cu_wanted |= (r[i] != 4 && r[i] != 2 && r[i] != 16 && r[i] != 8);
+        cu_wanted |= pfb_cu_direct_pays(nfft, avg);
     }
     if (cu_wanted) {
         bool taken = false;
@@ -1595,7 +1700,7 @@ bool pfb_cu_takes(int nfft, int avg, int len, bool bluestein) {
         int r[16];
         const int nr = pfb_lds_plan(nfft, r);
         if (cu_mode == 0 || nr < 0) return false;
-        bool wanted = cu_mode == 1;
+        bool wanted = cu_mode == 1 || pfb_cu_direct_pays(nfft, avg);
         for (int i = 0; i < nr; ++i) wanted |= (r[i] != 4 && r[i] != 2 && r[i] != 16 && r[i] != 8);
         if (!wanted) return false;
     }
