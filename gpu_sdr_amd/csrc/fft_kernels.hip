@@ -873,10 +873,10 @@ __device__ __forceinline__ void lds_stage_prime_first_mfma32(int R, const float2
 // all stages of a.radices over FR frames of `len` points; returns where the result is
 // (buffers are named by their OFFSET in the LDS array, not by pointer: a pointer that is swapped in a loop or
 //  picked by a comparison loses its address space and every ds_read behind it turns into a flat_load)
+template <int NT>
 __device__ __forceinline__ int pfb_cu_stages(const PfbCuArgs &a, float2 *lds, int src_off, int dst_off, const float2 *tw,
                                              const float2 *roots, int st_radix, int st_mag_t, int st_mag_p,
                                              int st_t, int st_tws, int tid, int s0, int s1, int &p) {
-    constexpr int NT = kPfbCuThreads;
     const int len = a.len, FR = a.G;
     for (int s = s0; s < s1; ++s) {
         float2 *src = lds + src_off, *dst = lds + dst_off;
@@ -919,9 +919,8 @@ __device__ __forceinline__ int pfb_cu_stages(const PfbCuArgs &a, float2 *lds, in
 // the frame-per-workgroup kernel issues four (every frame reloads its three shared blocks) and the staged path of this
 // kernel puts a trip through the LDS and a barrier in between -- then forms every frame of the run from registers
 // (float accumulation in tap order, ref cpp/kernels.cu:474-516).  All loads of a thread are in flight together.
-template <int CPT, int NB, bool GROUPS>
+template <int CPT, int NB, bool GROUPS, int NT>
 __device__ __forceinline__ void pfb_cu_filter_direct(const PfbCuArgs &a, float2 *A, int f0, int Gw, int tid) {
-    constexpr int NT = kPfbCuThreads;
     const int n = a.n, len = a.len;
     // GROUPS (frames of at most half the workgroup): the threads form dir_s groups of n, group g takes the dir_gs
     // consecutive frames from g * dir_gs on (their dir_gs + 3 blocks); otherwise one group takes the whole run -- a
@@ -980,9 +979,11 @@ __device__ __forceinline__ void pfb_cu_filter_direct(const PfbCuArgs &a, float2 
 
 // TWL: the twiddle table is copied into the LDS (a template parameter, not a run-time choice between an LDS and a
 // global pointer: that would be a flat pointer)
-template <bool TWL>
-__global__ __launch_bounds__(kPfbCuThreads) GSDR_NO_PK void pfb_cu_kernel(const PfbCuArgs a) {
-    constexpr int NT = kPfbCuThreads;
+// NT: 1024 threads, one workgroup per compute unit -- or 512, two per unit with half the frames each (the direct
+// filter only: it needs no raw samples in the LDS): two workgroups drift apart, one computes while the other waits
+// at a barrier or for its loads, where the sixteen waves of one workgroup meet at every barrier in step
+template <bool TWL, int NT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) GSDR_NO_PK void pfb_cu_kernel(const PfbCuArgs a) {
     extern __shared__ float2 pfb_lds[];
     const int tid = threadIdx.x, n = a.n, len = a.len, G = a.G;
     const unsigned padded = a.blocks_per_xcd * 8u;
@@ -1018,10 +1019,11 @@ __global__ __launch_bounds__(kPfbCuThreads) GSDR_NO_PK void pfb_cu_kernel(const 
         if (a.sel)
             for (int u = tid; u < a.n_out; u += NT) sel_l[u] = a.sel[u];
         switch (a.direct) {
-            case 1: pfb_cu_filter_direct<1, 11, false>(a, A, f0, Gw, tid); break;
-            case 2: pfb_cu_filter_direct<2, 7, false>(a, A, f0, Gw, tid); break;
-            case 3: pfb_cu_filter_direct<4, 4, false>(a, A, f0, Gw, tid); break;
-            default: pfb_cu_filter_direct<1, 11, true>(a, A, f0, Gw, tid); break;
+            case 1: pfb_cu_filter_direct<1, 11, false, NT>(a, A, f0, Gw, tid); break;
+            case 2: pfb_cu_filter_direct<2, 7, false, NT>(a, A, f0, Gw, tid); break;
+            case 3: pfb_cu_filter_direct<4, 4, false, NT>(a, A, f0, Gw, tid); break;
+            case 5: pfb_cu_filter_direct<3, 5, false, NT>(a, A, f0, Gw, tid); break;
+            default: pfb_cu_filter_direct<1, 11, true, NT>(a, A, f0, Gw, tid); break;
         }
         fft_stamp(1);
     } else {
@@ -1161,8 +1163,8 @@ __global__ __launch_bounds__(kPfbCuThreads) GSDR_NO_PK void pfb_cu_kernel(const 
     // ---- 3. the transform of all G frames, stage by stage ----
     const float2 *tw = TWL ? twl : a.tw;
     int pp = 1;
-    int res_off = pfb_cu_stages(a, pfb_lds, 0, a.b_off, tw, roots, st_radix, st_mag_t, st_mag_p, st_t, st_tws, tid, 0, 1, pp);
-    res_off = pfb_cu_stages(a, pfb_lds, res_off, res_off == 0 ? a.b_off : 0, tw, roots, st_radix, st_mag_t, st_mag_p, st_t,
+    int res_off = pfb_cu_stages<NT>(a, pfb_lds, 0, a.b_off, tw, roots, st_radix, st_mag_t, st_mag_p, st_t, st_tws, tid, 0, 1, pp);
+    res_off = pfb_cu_stages<NT>(a, pfb_lds, res_off, res_off == 0 ? a.b_off : 0, tw, roots, st_radix, st_mag_t, st_mag_p, st_t,
                             st_tws, tid, 1, a.n_radices, pp);
     if (a.chirp) {
         // d = conj(A * Bhat); the inverse transform is then a forward one (IFFT(z) = conj(FFT(conj z)) / m)
@@ -1174,7 +1176,7 @@ __global__ __launch_bounds__(kPfbCuThreads) GSDR_NO_PK void pfb_cu_kernel(const 
         }
         __syncthreads();
         pp = 1;
-        res_off = pfb_cu_stages(a, pfb_lds, res_off, res_off == 0 ? a.b_off : 0, tw, roots, st_radix, st_mag_t, st_mag_p,
+        res_off = pfb_cu_stages<NT>(a, pfb_lds, res_off, res_off == 0 ? a.b_off : 0, tw, roots, st_radix, st_mag_t, st_mag_p,
                                 st_t, st_tws, tid, 0, a.n_radices, pp);
     }
     const float2 *res = pfb_lds + res_off;
@@ -1478,17 +1480,18 @@ static bool pfb_cu_direct_pays(int nfft, int avg) {
 // Shape of the run-per-compute-unit kernel for frames of nfft points transformed at length `len` (nfft, or
 // Bluestein's m): frames per workgroup G (at most `want`), the offset and size of the second LDS buffer, whether
 // the twiddle table fits beside them.  False when not even one frame fits.
-static bool pfb_cu_shape(int nfft, int avg, int len, int want, int &G, int &b_off, int &b_len, int &twl, size_t &bytes) {
+static bool pfb_cu_shape(int nfft, int avg, int len, int want, int &G, int &b_off, int &b_len, int &twl, size_t &bytes,
+                         int threads = kPfbCuThreads, long long max_bytes = kPfbCuMaxBytes, bool staged = true) {
     for (G = want < 1 ? 1 : want; G >= 1; --G) {
-        if ((long long)G * nfft > (long long)kPfbCuPts * kPfbCuThreads) continue;
+        if (staged && (long long)G * nfft > (long long)kPfbCuPts * threads) continue;
         const long long al = ((long long)G * len + 1) & ~1LL;                 // even: 16-byte LDS stores into the buffer behind
-        long long bl = (long long)(G + avg - 1) * nfft;
+        long long bl = staged ? (long long)(G + avg - 1) * nfft : 0;          // (the direct filter stages no raw samples)
         if (bl < (long long)G * len) bl = (long long)G * len;
         bl = (bl + 1) & ~1LL;
         for (twl = len <= kPfbLdsTwMaxN ? 1 : 0; twl >= 0; --twl) {
             // + the bin table (n_out <= nfft ints)
             const long long total = (al + bl + kPfbLdsMaxPrime + 1 + (twl ? len : 0) + (nfft + 1) / 2) * (long long)sizeof(float2);
-            if (total <= kPfbCuMaxBytes) {
+            if (total <= max_bytes) {
                 b_off = (int)al;
                 b_len = (int)bl;
                 bytes = (size_t)total;
@@ -1533,29 +1536,54 @@ static hipError_t launch_pfb_cu(const float2 *carry, int new_0, const float2 *in
     int want = frames_n > 0 ? (frames_n + cus - 1) / cus : 1;
     size_t lds = 0;
     if (n_out > nfft) return hipSuccess;                  // the bin table in the LDS is sized for n_out <= nfft
-    if (!pfb_cu_shape(nfft, avg, len, want, a.G, a.b_off, a.b_len, a.twl, lds)) return hipSuccess;    // does not fit: the caller's other kernel
+    // the direct filter's variant for G frames on `threads` threads: 0 = none
+    // (GSDR_PFB_DIRECT=0: staged through the LDS; GSDR_PFB_COL=0/1, GSDR_PFB_CU_NT=512/1024: A/B runs)
+    static const int direct_env = [] { const char *e = std::getenv("GSDR_PFB_DIRECT"); return e ? std::atoi(e) : 1; }();
+    static const int col_env = [] { const char *e = std::getenv("GSDR_PFB_COL"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    static const int nt_env = [] { const char *e = std::getenv("GSDR_PFB_CU_NT"); return e ? std::atoi(e) : 0; }();
+    auto direct_variant = [&](int G, int threads, int &dir_s, int &dir_gs) {
+        const int cpt = (nfft + threads - 1) / threads;
+        dir_s = cpt == 1 ? threads / nfft : 1;             // groups of threads (frames shorter than the workgroup)
+        dir_gs = (G + dir_s - 1) / dir_s;                  // frames per group
+        const int nb = dir_gs + 3;
+        if (avg != 4 || !direct_env) return 0;
+        if (cpt == 1 && nb <= 11) return dir_s > 1 ? 4 : 1;
+        if (cpt <= 2 && nb <= 7) return 2;
+        if (cpt <= 3 && nb <= 5) return 5;
+        if (cpt <= 4 && nb <= 4) return 3;
+        return 0;
+    };
+    int threads = kPfbCuThreads;
+    a.direct = 0;
+    // two workgroups of 512 threads per unit, half the frames each, when the direct filter takes them -- for frames
+    // below 1024 points without a matrix-core stage: same box, 128 ... 512 points 9.7 - 10.0 against 10.2 - 10.3 us,
+    // 1000: 12.4 / 12.9; from 1024 points on the full workgroup wins (1024: 10.9 against 11.2, 2048: 10.5 / 11.9,
+    // and the matrix-core stage wants its sixteen waves: 1230: 13.5 / 17.0), profiles/r03_pfb_ab_nt.log
+    const bool half_pays = nt_env == 512 || (nt_env == 0 && nfft < 1024 && !(a.n_radices > 0 && a.radices[0] > 13));
+    if (half_pays && avg == 4 && direct_env) {
+        const int want2 = frames_n > 0 ? (frames_n + 2 * cus - 1) / (2 * cus) : 1;
+        int G2 = 0, bo = 0, bl = 0, twl2 = 0, ds = 1, dg = 1;
+        size_t lds2 = 0;
+        if (pfb_cu_shape(nfft, avg, len, want2, G2, bo, bl, twl2, lds2, 512, kPfbCuMaxBytes / 2, false)) {
+            const int v = direct_variant(G2, 512, ds, dg);
+            if (v) {
+                threads = 512;
+                a.G = G2; a.b_off = bo; a.b_len = bl; a.twl = twl2; lds = lds2;
+                a.direct = v; a.dir_s = ds; a.dir_gs = dg; a.col = 1;
+            }
+        }
+    }
+    if (threads == kPfbCuThreads) {
+        if (!pfb_cu_shape(nfft, avg, len, want, a.G, a.b_off, a.b_len, a.twl, lds)) return hipSuccess;    // does not fit: the caller's other kernel
+        // column-wise filter: four taps, and enough columns for every thread
+        a.col = avg == 4 && (col_env < 0 ? nfft >= kPfbCuThreads / 2 : col_env == 1);
+        a.direct = direct_variant(a.G, kPfbCuThreads, a.dir_s, a.dir_gs);
+    }
     a.carry = carry; a.in = in; a.window = window; a.tw = tw; a.sel = sel; a.out = out; a.carry_out = carry_out;
     a.chirp = blue ? blue->d_chirp : nullptr;
     a.bhat = blue ? blue->d_bhat : nullptr;
     a.n = nfft; a.F = avg; a.frames_n = frames_n; a.n_out = n_out; a.new_0 = new_0; a.len = len;
     a.spare_begin = spare_begin; a.spare_n = spare_n;
-    {
-        // column-wise filter: four taps, and enough columns for every thread (GSDR_PFB_COL=0/1: A/B runs)
-        static const int col_env = [] { const char *e = std::getenv("GSDR_PFB_COL"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
-        a.col = avg == 4 && (col_env < 0 ? nfft >= kPfbCuThreads / 2 : col_env == 1);
-        // ... and straight out of global memory when the run's blocks fit the registers (GSDR_PFB_DIRECT=0: staged)
-        static const int direct_env = [] { const char *e = std::getenv("GSDR_PFB_DIRECT"); return e ? std::atoi(e) : 1; }();
-        const int cpt = (nfft + kPfbCuThreads - 1) / kPfbCuThreads;
-        a.dir_s = cpt == 1 ? kPfbCuThreads / nfft : 1;     // groups of threads (frames shorter than the workgroup)
-        a.dir_gs = (a.G + a.dir_s - 1) / a.dir_s;          // frames per group
-        const int nb = a.dir_gs + 3;
-        a.direct = 0;
-        if (avg == 4 && direct_env) {
-            if (cpt == 1 && nb <= 11) a.direct = a.dir_s > 1 ? 4 : 1;
-            else if (cpt <= 2 && nb <= 7) a.direct = 2;
-            else if (cpt <= 4 && nb <= 4) a.direct = 3;
-        }
-    }
     a.main_blocks = (unsigned)((frames_n + a.G - 1) / a.G);
     auto magic = [](long long d) { return d <= 1 ? 0u : (unsigned)(0x100000000ULL / (unsigned long long)d + 1ULL); };
     a.mag_n = magic(nfft);
@@ -1582,15 +1610,17 @@ static hipError_t launch_pfb_cu(const float2 *carry, int new_0, const float2 *in
     if (a.main_blocks + spare_blocks == 0) return hipSuccess;
     static std::atomic<unsigned long long> attr_done{0};
     if (!(attr_done.load() >> dev & 1ULL)) {
-        for (const void *f : {reinterpret_cast<const void *>(pfb_cu_kernel<true>), reinterpret_cast<const void *>(pfb_cu_kernel<false>)}) {
+        for (const void *f : {reinterpret_cast<const void *>(pfb_cu_kernel<true, 1024>), reinterpret_cast<const void *>(pfb_cu_kernel<false, 1024>),
+                              reinterpret_cast<const void *>(pfb_cu_kernel<true, 512>), reinterpret_cast<const void *>(pfb_cu_kernel<false, 512>)}) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kPfbCuMaxBytes);
             if (e != hipSuccess) return e;
         }
         attr_done.fetch_or(1ULL << dev);
     }
     void *kargs[] = {&a};
-    const void *fn = a.twl ? reinterpret_cast<const void *>(pfb_cu_kernel<true>) : reinterpret_cast<const void *>(pfb_cu_kernel<false>);
-    return hipLaunchKernel(fn, dim3(a.blocks_per_xcd * 8u + spare_blocks), dim3(kPfbCuThreads), kargs, lds, st);
+    const void *fn = threads == 512 ? (a.twl ? reinterpret_cast<const void *>(pfb_cu_kernel<true, 512>) : reinterpret_cast<const void *>(pfb_cu_kernel<false, 512>))
+                                    : (a.twl ? reinterpret_cast<const void *>(pfb_cu_kernel<true, 1024>) : reinterpret_cast<const void *>(pfb_cu_kernel<false, 1024>));
+    return hipLaunchKernel(fn, dim3(a.blocks_per_xcd * 8u + spare_blocks), dim3(threads), kargs, lds, st);
 }
 
 hipError_t launch_pfb_lds(const float2 *carry, int new_0, const float2 *in, const float *window, const float2 *tw,
