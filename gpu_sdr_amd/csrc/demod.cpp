@@ -1180,7 +1180,7 @@ gsdr_demod *gsdr_demod_create(const gsdr_param_c *p) {
                 h->pfb_blue = blue_ok;
                 h->F = F;
                 h->M = h->nfft;
-                h->pfb_cu = gsdr::pfb_cu_takes(h->nfft, F, blue_ok ? (int)blue_m : h->nfft, blue_ok);
+                h->pfb_cu = gsdr::pfb_cu_takes(h->nfft, F, blue_ok ? (int)blue_m : h->nfft, blue_ok, (int)(h->L / h->nfft));
                 h->kernel_name = h->pfb_cu ? gsdr::pfb_cu_kernel_name() : gsdr::pfb_lds_kernel_name();
                 std::vector<float2> tw((size_t)h->nfft);
                 for (int k = 0; k < h->nfft; ++k) {

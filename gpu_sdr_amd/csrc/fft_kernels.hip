@@ -1502,10 +1502,35 @@ static bool pfb_cu_shape(int nfft, int avg, int len, int want, int &G, int &b_of
     return false;
 }
 
+// Long frames, few of them: the run kernel gives every compute unit ceil(frames / units) frames, and with 325 frames
+// of 3072 points that is two for 163 units and none for the rest (21 us per buffer against 15 a frame per workgroup,
+// two workgroups per unit; profiles/r03_pfb_ab_4096.log).  The share of (unit, frame) slots a launch fills; below
+// 0.7 the frame-per-workgroup kernel takes the call where it can (no matrix-core stage, no Bluestein).
+static double pfb_cu_fill(int nfft, int avg, int len, int frames_n, int cus) {
+    if (frames_n <= 0 || cus <= 0) return 1.0;
+    const int want = (frames_n + cus - 1) / cus;
+    int G = 0, bo, bl, twl;
+    size_t bytes;
+    if (!pfb_cu_shape(nfft, avg, len, want, G, bo, bl, twl, bytes) &&
+        !pfb_cu_shape(nfft, avg, len, want, G, bo, bl, twl, bytes, kPfbCuThreads, kPfbCuMaxBytes, false))
+        return 1.0;
+    const long long blocks = (frames_n + G - 1) / G, rounds = (blocks + cus - 1) / cus;
+    return (double)frames_n / ((double)G * cus * rounds);
+}
+static bool pfb_cu_has_big_prime(int nfft) {
+    int r[16];
+    const int nr = pfb_lds_plan(nfft, r);
+    return nr > 0 && r[0] > 13;
+}
+
 bool pfb_cu_fits(int nfft, int avg, int len) {
     int G, bo, bl, twl;
     size_t bytes;
-    return nfft >= 1 && avg >= 1 && len >= nfft && len <= kPfbLdsMaxN && pfb_cu_shape(nfft, avg, len, 1, G, bo, bl, twl, bytes);
+    if (!(nfft >= 1 && avg >= 1 && len >= nfft && len <= kPfbLdsMaxN)) return false;
+    if (pfb_cu_shape(nfft, avg, len, 1, G, bo, bl, twl, bytes)) return true;
+    // the direct filter keeps no raw samples in the LDS: a frame of up to four columns per thread fits without them
+    return pfb_cu_direct_pays(nfft, avg) && nfft <= 4 * kPfbCuThreads &&
+           pfb_cu_shape(nfft, avg, len, 1, G, bo, bl, twl, bytes, kPfbCuThreads, kPfbCuMaxBytes, false);
 }
 
 static hipError_t launch_pfb_cu(const float2 *carry, int new_0, const float2 *in, const float *window, const float2 *tw,
@@ -1574,10 +1599,24 @@ static hipError_t launch_pfb_cu(const float2 *carry, int new_0, const float2 *in
         }
     }
     if (threads == kPfbCuThreads) {
-        if (!pfb_cu_shape(nfft, avg, len, want, a.G, a.b_off, a.b_len, a.twl, lds)) return hipSuccess;    // does not fit: the caller's other kernel
-        // column-wise filter: four taps, and enough columns for every thread
-        a.col = avg == 4 && (col_env < 0 ? nfft >= kPfbCuThreads / 2 : col_env == 1);
-        a.direct = direct_variant(a.G, kPfbCuThreads, a.dir_s, a.dir_gs);
+        if (pfb_cu_shape(nfft, avg, len, want, a.G, a.b_off, a.b_len, a.twl, lds)) {
+            // column-wise filter: four taps, and enough columns for every thread
+            a.col = avg == 4 && (col_env < 0 ? nfft >= kPfbCuThreads / 2 : col_env == 1);
+            a.direct = direct_variant(a.G, kPfbCuThreads, a.dir_s, a.dir_gs);
+        } else {
+            // no room for the raw samples of a run: the direct filter needs none (4096 points: a frame per unit)
+            if (!pfb_cu_shape(nfft, avg, len, want, a.G, a.b_off, a.b_len, a.twl, lds, kPfbCuThreads, kPfbCuMaxBytes, false))
+                return hipSuccess;                         // does not fit: the caller's other kernel
+            a.col = 1;
+            while (a.G >= 1 && !(a.direct = direct_variant(a.G, kPfbCuThreads, a.dir_s, a.dir_gs))) --a.G;
+            if (a.G < 1) return hipSuccess;
+        }
+    }
+    {
+        static const int cu_forced = [] { const char *e = std::getenv("GSDR_PFB_CU"); return e && e[0] == '1'; }();
+        if (!blue && !cu_forced && threads == kPfbCuThreads && !(a.n_radices > 0 && a.radices[0] > 13) &&
+            pfb_cu_fill(nfft, avg, len, frames_n, cus) < 0.7)
+            return hipSuccess;                             // the frame-per-workgroup kernel fills the chip better
     }
     a.carry = carry; a.in = in; a.window = window; a.tw = tw; a.sel = sel; a.out = out; a.carry_out = carry_out;
     a.chirp = blue ? blue->d_chirp : nullptr;
@@ -1635,10 +1674,10 @@ hipError_t launch_pfb_lds(const float2 *carry, int new_0, const float2 *in, cons
         (long long)spare_begin + spare_n > window_len || new_0 > window_len || window_len > 0x7fffffffLL - nfft)
         return hipErrorInvalidValue;
     // A run of frames per compute unit (round 3) when the run fits the LDS and the length has a stage other than
-    // radix 4 / 2 -- a prime above 13 (its stage runs on the matrix cores there), 3, 5, 7 ... -- or goes through
-    // Bluestein: measured per 1 M-sample buffer (profiles/r03_pfb_sweep.log) 1230 points 19.7 -> 15.5 us, 1016
-    // 21.5 -> 16.1, 1000 15.7 -> 14.5; pure powers of two are 3 - 8 % FASTER a frame per workgroup (1024: 12.7
-    // against 13.1 us, 64 ... 256: 10.0 / 10.8 against 10.7 / 11.6) and stay there.  GSDR_PFB_CU=0 / 1 forces.
+    // radix 2 / 4 / 8 / 16 -- a prime above 13 (its stage runs on the matrix cores there), 3, 5, 7 ... --, goes
+    // through Bluestein, or has four taps and at least 128 points (the direct filter, pfb_cu_direct_pays()).
+    // Measured per 1 M-sample buffer (profiles/r03_pfb_sweep.log): 1230 points 19.7 -> 13.1 us, 1016: 21.5 -> 13.5,
+    // 1024: 12.6 -> 10.9.  GSDR_PFB_CU=0 / 1 forces.
     static const int cu_mode = [] { const char *e = std::getenv("GSDR_PFB_CU"); return e && e[0] ? (e[0] == '0' ? 0 : 1) : -1; }();
     bool cu_wanted = cu_mode == 1 || blue != nullptr;
     if (cu_mode < 0 && !blue) {
@@ -1724,7 +1763,7 @@ hipError_t launch_pfb_lds(const float2 *carry, int new_0, const float2 *in, cons
 const char *pfb_lds_kernel_name() { return "pfb_lds_kernel"; }
 const char *pfb_cu_kernel_name() { return "pfb_cu_kernel"; }
 // which of the two kernels launch_pfb_lds() runs for this shape (describe(), the profiler's name)
-bool pfb_cu_takes(int nfft, int avg, int len, bool bluestein) {
+bool pfb_cu_takes(int nfft, int avg, int len, bool bluestein, int frames_per_call) {
     static const int cu_mode = [] { const char *e = std::getenv("GSDR_PFB_CU"); return e && e[0] ? (e[0] == '0' ? 0 : 1) : -1; }();
     if (!bluestein) {
         int r[16];
@@ -1733,6 +1772,11 @@ bool pfb_cu_takes(int nfft, int avg, int len, bool bluestein) {
         bool wanted = cu_mode == 1 || pfb_cu_direct_pays(nfft, avg);
         for (int i = 0; i < nr; ++i) wanted |= (r[i] != 4 && r[i] != 2 && r[i] != 16 && r[i] != 8);
         if (!wanted) return false;
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+            cus = 256;
+        if (cu_mode != 1 && nfft >= kPfbCuThreads && !pfb_cu_has_big_prime(nfft) && pfb_cu_fill(nfft, avg, len, frames_per_call, cus) < 0.7)
+            return false;
     }
     return pfb_cu_fits(nfft, avg, len);
 }

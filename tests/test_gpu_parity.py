@@ -767,7 +767,10 @@ NOISE_FFT_CASES = [
     (1021, 2, 30_000, 3),                      # a prime frame through 2048
     (3 * 1009, 2, 40_000, 3),                  # 3027 -> 8192: the longest Bluestein length the LDS takes
     (2048, 4, 100_000, 2),                     # two frames per compute unit at most: the run kernel's LDS limit
-    (4096, 4, 100_000, 2),                     # a frame does not fit the run kernel: the frame-per-workgroup kernel
+    (4096, 4, 100_000, 2),                     # no room for a run's raw samples in the LDS: four taps filter straight out of memory
+    (4096, 3, 100_000, 2),                     # ... three taps do not: the frame-per-workgroup kernel
+    (3001, 4, 40_000, 3),                      # a prime frame through 8192 with the direct filter (two buffers of 8192 fill the LDS)
+    (3072, 4, 200_000, 2),                     # 16 16 4 3, 65 frames per call: too few to fill the run kernel's units
     (250, 4, 20_000, 3),                       # 10 5 5: the radix-10 butterfly (a 2 joined with a 5)
     (70, 3, 5_000, 3),                         # 7 10
     (600, 4, 30_000, 3),                       # 8 5 5 3; column-wise filter (four taps, >= 512 columns)
@@ -814,7 +817,8 @@ PFB_LDS_KERNELS = ("pfb_cu_kernel", "pfb_lds_kernel")     # a run of frames per 
 def pfb_lds_fits(nfft, avg=4):
     """Lengths TONES / NOISE run inside the LDS in one launch: up to 8192 points without a prime factor above 127
     (radix stages over the frame length), or -- round 3 -- any length whose Bluestein length m = 2^ceil(log2(2n-1))
-    is at most 8192 and fits the run kernel's LDS layout (a buffer of m points plus one of max(m, avg*n))."""
+    is at most 8192 and fits the run kernel's LDS layout (a buffer of m points plus one of max(m, avg*n); with four
+    taps plus one of m: the direct filter keeps no raw samples there)."""
     m, q, largest = nfft, 2, 1
     while m > 1:
         while m % q == 0:
@@ -827,7 +831,12 @@ def pfb_lds_fits(nfft, avg=4):
     while mm < 2 * nfft - 1:
         mm *= 2
     even = lambda v: (v + 1) & ~1
-    return mm <= 8192 and (even(mm) + even(max(mm, avg * nfft)) + 128 + (nfft + 1) // 2) * 8 <= 156 * 1024
+    if mm > 8192:
+        return False
+    if (even(mm) + even(max(mm, avg * nfft)) + 128 + (nfft + 1) // 2) * 8 <= 156 * 1024:
+        return True
+    # four taps, 128 points and more: the filter runs straight out of global memory and the second buffer holds no raw samples
+    return avg == 4 and 128 <= nfft <= 4096 and (2 * even(mm) + 128 + (nfft + 1) // 2) * 8 <= 156 * 1024
 
 
 @pytest.mark.parametrize("path", ["lds", "global"])

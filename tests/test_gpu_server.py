@@ -48,7 +48,7 @@ def recv_async(sock):
 def connect(port, tries=100):
     for _ in range(tries):
         try:
-            return socket.create_connection(("127.0.0.1", port), timeout=60)
+            return socket.create_connection(("127.0.0.1", port), timeout=180)    # (generous: a shared box has stalled a reply for a minute once)
         except OSError:
             time.sleep(0.1)
     raise ConnectionError(port)
