@@ -86,6 +86,7 @@ SIGNATURES = [
     ("gsdr_last_error", C.c_char_p, [_vp]),
     ("gsdr_abi_version", C.c_int, []),
     ("gsdr_build_info", C.c_char_p, []),
+    ("gsdr_reload_env", None, []),
     ("gsdr_demod_describe", C.c_int, [_vp, C.c_char_p, C.c_int]),
     ("gsdr_demod_mode", C.c_int, [_vp]),
     ("gsdr_demod_channels", C.c_int, [_vp]),

@@ -190,6 +190,7 @@ hipError_t launch_pfb_lds(const float2 *carry, int new_0, const float2 *in, cons
 const char *pfb_lds_kernel_name();
 const char *pfb_cu_kernel_name();
 bool pfb_cu_fits(int nfft, int avg, int len);                      // does one frame fit the run kernel's LDS layout
+void fft_env_reload();                                              // the cached GSDR_PFB_* switches are read again
 bool pfb_cu_takes(int nfft, int avg, int len, bool bluestein, int frames_per_call);     // ... and is it the kernel launch_pfb_lds() runs (for calls of about that many frames)
 
 // ---- chirp ---------------------------------------------------------------

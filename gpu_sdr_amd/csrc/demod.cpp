@@ -1732,6 +1732,8 @@ int gsdr_demod_profile_read(gsdr_demod *h, double *total_ms) {
 
 const char *gsdr_demod_kernel_name(const gsdr_demod *h) { return h ? h->kernel_name : "none"; }
 
+void gsdr_reload_env(void) { gsdr::fft_env_reload(); }
+
 const char *gsdr_build_info(void) {
 #ifdef GSDR_TIMING_BUILD
     return "abi 1; arch gfx950; timing_build 1";

@@ -27,6 +27,31 @@
 
 namespace gsdr {
 
+// The GSDR_PFB_* switches below exist for A/B runs and for the tests that drive every kernel variant.  They are read
+// once and cached (a launch must not walk the environment); gsdr_reload_env() (include/gsdr.h) makes the next use
+// read them again.
+static std::atomic<int> g_env_generation{0};
+void fft_env_reload() { g_env_generation.fetch_add(1); }
+namespace {
+struct EnvSwitch {
+    const char *name;
+    int unset;                 // value when the variable is not set (or empty)
+    std::atomic<int> seen{-1}, value{0};
+    EnvSwitch(const char *n, int u) : name(n), unset(u) {}
+    int get() {
+        const int g = g_env_generation.load(std::memory_order_relaxed);
+        if (seen.load(std::memory_order_acquire) != g) {
+            const char *e = std::getenv(name);
+            value.store(e && e[0] ? std::atoi(e) : unset, std::memory_order_relaxed);
+            seen.store(g, std::memory_order_release);
+        }
+        return value.load(std::memory_order_relaxed);
+    }
+};
+EnvSwitch env_radix8{"GSDR_PFB_RADIX8", 1}, env_direct{"GSDR_PFB_DIRECT", 1}, env_col{"GSDR_PFB_COL", -1},
+    env_cu_nt{"GSDR_PFB_CU_NT", 0}, env_cu{"GSDR_PFB_CU", -1}, env_fr{"GSDR_PFB_FR", 0}, env_wide{"GSDR_PFB_WIDE", -1};
+}  // namespace
+
 // No packed FP32 in these kernels: a NOISE handle may run beside the matrix-core DDC of another handle
 // (two front-ends on one GPU), and v_pk_*_f32 with a high-half broadcast is unreliable in a wave that
 // shares its SIMD with an MFMA loop (rule R3, DESIGN.md section 4.1, tools/ubench_pk_hazard.hip).
@@ -1454,7 +1479,7 @@ int pfb_lds_plan(int n, int *radices) {
     //   * 8 (= 4 x 2) otherwise: one thread in eight points keeps half of the threads busy;
     //   * a single 2 left over joins a 3 or a 5: radix 6 / 10 (1230 = 41 * 6 * 5, 1000 = 8 * 5 * 5 * 5).
     // GSDR_PFB_RADIX8=0: 4s and 2s as in round 2 (A/B runs)
-    static const bool fat = [] { const char *e = std::getenv("GSDR_PFB_RADIX8"); return !(e && e[0] == '0'); }();
+    const bool fat = env_radix8.get() != 0;
     if (n >= 4096)
         while (m % 16 == 0) { push(16); m /= 16; }
     if (fat)
@@ -1473,7 +1498,7 @@ int pfb_lds_plan(int n, int *radices) {
 // 10.4 / 11.9; 16 points 9.9 against 9.4 and 64 points equal: short frames stay a frame set per workgroup
 // (profiles/r03_pfb_ab_direct.log).  GSDR_PFB_DIRECT=0 switches the direct filter off, and this rule with it.
 static bool pfb_cu_direct_pays(int nfft, int avg) {
-    static const int direct_env = [] { const char *e = std::getenv("GSDR_PFB_DIRECT"); return e ? std::atoi(e) : 1; }();
+    const int direct_env = env_direct.get();
     return direct_env && avg == 4 && nfft >= 128;
 }
 
@@ -1563,9 +1588,9 @@ static hipError_t launch_pfb_cu(const float2 *carry, int new_0, const float2 *in
     if (n_out > nfft) return hipSuccess;                  // the bin table in the LDS is sized for n_out <= nfft
     // the direct filter's variant for G frames on `threads` threads: 0 = none
     // (GSDR_PFB_DIRECT=0: staged through the LDS; GSDR_PFB_COL=0/1, GSDR_PFB_CU_NT=512/1024: A/B runs)
-    static const int direct_env = [] { const char *e = std::getenv("GSDR_PFB_DIRECT"); return e ? std::atoi(e) : 1; }();
-    static const int col_env = [] { const char *e = std::getenv("GSDR_PFB_COL"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
-    static const int nt_env = [] { const char *e = std::getenv("GSDR_PFB_CU_NT"); return e ? std::atoi(e) : 0; }();
+    const int direct_env = env_direct.get();
+    const int col_env = env_col.get() < 0 ? -1 : (env_col.get() != 0);
+    const int nt_env = env_cu_nt.get();
     auto direct_variant = [&](int G, int threads, int &dir_s, int &dir_gs) {
         const int cpt = (nfft + threads - 1) / threads;
         dir_s = cpt == 1 ? threads / nfft : 1;             // groups of threads (frames shorter than the workgroup)
@@ -1613,7 +1638,7 @@ static hipError_t launch_pfb_cu(const float2 *carry, int new_0, const float2 *in
         }
     }
     {
-        static const int cu_forced = [] { const char *e = std::getenv("GSDR_PFB_CU"); return e && e[0] == '1'; }();
+        const bool cu_forced = env_cu.get() == 1;
         if (!blue && !cu_forced && threads == kPfbCuThreads && !(a.n_radices > 0 && a.radices[0] > 13) &&
             pfb_cu_fill(nfft, avg, len, frames_n, cus) < 0.7)
             return hipSuccess;                             // the frame-per-workgroup kernel fills the chip better
@@ -1678,7 +1703,7 @@ hipError_t launch_pfb_lds(const float2 *carry, int new_0, const float2 *in, cons
     // through Bluestein, or has four taps and at least 128 points (the direct filter, pfb_cu_direct_pays()).
     // Measured per 1 M-sample buffer (profiles/r03_pfb_sweep.log): 1230 points 19.7 -> 13.1 us, 1016: 21.5 -> 13.5,
     // 1024: 12.6 -> 10.9.  GSDR_PFB_CU=0 / 1 forces.
-    static const int cu_mode = [] { const char *e = std::getenv("GSDR_PFB_CU"); return e && e[0] ? (e[0] == '0' ? 0 : 1) : -1; }();
+    const int cu_mode = env_cu.get() < 0 ? -1 : (env_cu.get() != 0);
     bool cu_wanted = cu_mode == 1 || blue != nullptr;
     if (cu_mode < 0 && !blue) {
         int r[16];
@@ -1707,8 +1732,8 @@ hipError_t launch_pfb_lds(const float2 *carry, int new_0, const float2 *in, cons
     a.spare_begin = spare_begin; a.spare_n = spare_n;
     // short frames share a workgroup: at least ~1024 points of work per workgroup
     a.FR = nfft >= 1024 ? 1 : (1024 + nfft - 1) / nfft;
-    static const int fr_env = [] { const char *e = std::getenv("GSDR_PFB_FR"); return e ? std::atoi(e) : 0; }();      // A/B runs
-    static const int wide_env = [] { const char *e = std::getenv("GSDR_PFB_WIDE"); return e ? std::atoi(e) : -1; }();
+    const int fr_env = env_fr.get();      // A/B runs
+    const int wide_env = env_wide.get();
     if (fr_env > 0 && (long long)fr_env * nfft <= 4096) a.FR = fr_env;
     if (a.FR > 64) a.FR = 64;
     a.main_blocks = (unsigned)((frames_n + a.FR - 1) / a.FR);
@@ -1764,7 +1789,7 @@ const char *pfb_lds_kernel_name() { return "pfb_lds_kernel"; }
 const char *pfb_cu_kernel_name() { return "pfb_cu_kernel"; }
 // which of the two kernels launch_pfb_lds() runs for this shape (describe(), the profiler's name)
 bool pfb_cu_takes(int nfft, int avg, int len, bool bluestein, int frames_per_call) {
-    static const int cu_mode = [] { const char *e = std::getenv("GSDR_PFB_CU"); return e && e[0] ? (e[0] == '0' ? 0 : 1) : -1; }();
+    const int cu_mode = env_cu.get() < 0 ? -1 : (env_cu.get() != 0);
     if (!bluestein) {
         int r[16];
         const int nr = pfb_lds_plan(nfft, r);

@@ -145,6 +145,10 @@ int gsdr_abi_version(void);
  * (-DGSDR_TIMING_BUILD, scratch/ only) whose kernels can be told to skip work;
  * the shipped library is always 0 and bench.py refuses anything else. */
 const char *gsdr_build_info(void);
+/* Diagnostic: the GSDR_PFB_* environment switches (A/B runs, kernel variants in the tests) are read
+ * once and cached -- a launch does not walk the environment.  This makes their next use read them again.  Handles
+ * created earlier keep the kernel NAME they reported; which kernel a call runs follows the new values. */
+void gsdr_reload_env(void);
 /* One-line JSON object describing the engine this handle resolved to: mode,
  * dominant kernel, kernel family, row tiles per workgroup, pipeline streams,
  * and every GSDR_* environment variable that was set in the process (the

@@ -877,6 +877,77 @@ def test_noise_fft_stage_parity(cuda_device, gsdr_lib, oracle_mod, monkeypatch, 
     dem.close()
 
 
+PFB_VARIANTS = [
+    # environment                      kernel the library must then run (None: its own choice stands), what the variant is
+    ({},                               None,             "the library's choice"),
+    ({"GSDR_PFB_CU": "0"},             "pfb_lds_kernel", "a frame (or a set of short frames) per workgroup"),
+    ({"GSDR_PFB_CU": "1"},             "pfb_cu_kernel",  "the run kernel, forced"),
+    ({"GSDR_PFB_DIRECT": "0"},         None,             "the run kernel's filter staged through the LDS, column-wise"),
+    ({"GSDR_PFB_DIRECT": "0", "GSDR_PFB_COL": "0"}, None, "... staged, point-wise"),
+    ({"GSDR_PFB_CU": "1", "GSDR_PFB_CU_NT": "1024"}, "pfb_cu_kernel", "one workgroup of 1024 threads per unit"),
+    ({"GSDR_PFB_CU": "1", "GSDR_PFB_CU_NT": "512"},  "pfb_cu_kernel", "two workgroups of 512 threads per unit where the direct filter takes them"),
+    ({"GSDR_PFB_RADIX8": "0"},         None,             "radix 4 / 2 stages only"),
+]
+PFB_VARIANT_SHAPES = [
+    # nfft, avg, L, buffers
+    (64, 4, 9_000, 3),        # short frames: thread groups in the direct filter
+    (200, 4, 30_011, 3),      # 8 5 5, groups that do not divide the workgroup, L not a multiple of the frame
+    (512, 4, 700, 8),         # calls without a frame (the carry alone moves), then one
+    (1024, 4, 60_000, 3),     # one column per thread
+    (1230, 4, 60_000, 3),     # two columns per thread, matrix-core first stage (41)
+    (1536, 4, 60_000, 2),     # two columns, 8 8 8 3
+    (2600, 4, 80_000, 2),     # three columns per thread
+    (4096, 4, 100_000, 2),    # four columns, a frame per unit
+    (1018, 4, 40_000, 2),     # 2 * 509: Bluestein through 2048 (the run kernel under every switch but GSDR_PFB_CU=0)
+]
+
+
+@pytest.mark.parametrize("env,kernel,what", PFB_VARIANTS,
+                         ids=["+".join(f"{k[9:]}={x}" for k, x in v[0].items()) or "default" for v in PFB_VARIANTS])
+@pytest.mark.parametrize("nfft,avg,L,nbuf", PFB_VARIANT_SHAPES, ids=lambda v: str(v))
+def test_noise_every_kernel_variant(cuda_device, gsdr_lib, oracle_mod, monkeypatch, nfft, avg, L, nbuf, env, kernel, what):
+    """Every variant of the in-LDS TONES / NOISE kernels on the same inputs against the oracle:
+    the switches are the A/B switches of the library (GSDR_PFB_*), re-read through gsdr_reload_env().  The default
+    suite only sees the variant the library picks for a shape."""
+    import gpu_sdr_amd as g
+    from gpu_sdr_amd import _lib
+    for k in ("GSDR_PFB_CU", "GSDR_PFB_DIRECT", "GSDR_PFB_COL", "GSDR_PFB_CU_NT", "GSDR_PFB_RADIX8"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    _lib.lib().gsdr_reload_env()
+    try:
+        rng = np.random.default_rng(5200 + nfft)
+        p = g.param(mode="RX", rate=1_000_000, buffer_len=L, decim=0, pf_average=avg, fft_tones=nfft,
+                    freq=[0], wave_type=[g.w_type.NOISE])
+        dem = g.RX_buffer_demodulator(p, device_index=0)
+        blue = nfft == 1018
+        if blue and env.get("GSDR_PFB_CU") == "0":
+            dem.close()
+            pytest.skip("Bluestein inside the LDS is the run kernel's")
+        if kernel is not None and not blue and not (kernel == "pfb_cu_kernel" and nfft > 4096):
+            assert dem.kernel_name == kernel, what
+        assert dem.kernel_name in PFB_LDS_KERNELS
+        ref = oracle_mod.Noise(nfft, avg, L)
+        emitted = 0
+        for c in range(nbuf):
+            x = crandn(rng, L)
+            y = (run_host if c % 2 else run_device)(dem, x, *(() if c % 2 else (cuda_device,)))
+            yr = ref.process(x)
+            assert y.size == yr.size, (c, y.size, yr.size)
+            if yr.size:
+                emitted += 1
+                e_all = float(np.linalg.norm(y.reshape(-1, nfft) - yr) / np.linalg.norm(yr))
+                record_margin(e_all, "all bins together")
+                assert e_all <= TOL, what
+        assert emitted >= 1
+        dem.close()
+    finally:
+        for k in env:
+            monkeypatch.delenv(k, raising=False)
+        _lib.lib().gsdr_reload_env()
+
+
 def test_noise_beyond_16384_bins(cuda_device, gsdr_lib):
     """fft_tones > 16384 (refused in round 1, where every bin was a DDC tone): 20000 = 4^2 2 5^4
     and 65536 bins, 1 M-sample buffers, against numpy's double-precision FFT of the same
