@@ -49,7 +49,8 @@ struct EnvSwitch {
     }
 };
 EnvSwitch env_radix8{"GSDR_PFB_RADIX8", 1}, env_direct{"GSDR_PFB_DIRECT", 1}, env_col{"GSDR_PFB_COL", -1},
-    env_cu_nt{"GSDR_PFB_CU_NT", 0}, env_cu{"GSDR_PFB_CU", -1}, env_fr{"GSDR_PFB_FR", 0}, env_wide{"GSDR_PFB_WIDE", -1};
+    env_cu_nt{"GSDR_PFB_CU_NT", 0}, env_cu{"GSDR_PFB_CU", -1}, env_fr{"GSDR_PFB_FR", 0}, env_wide{"GSDR_PFB_WIDE", -1},
+    env_teams{"GSDR_PFB_TEAMS", 1};
 }  // namespace
 
 // No packed FP32 in these kernels: a NOISE handle may run beside the matrix-core DDC of another handle
@@ -631,6 +632,7 @@ struct PfbCuArgs {
     int col;                   // the filter works column-wise (see the kernel)
     int direct;                // ... and straight out of global memory: 1: <1, 11>, 2: <2, 7>, 3: <4, 4> (columns per thread, blocks), 4: <1, 11> in groups
     int dir_s, dir_gs;         // frames shorter than the workgroup: dir_s groups of threads take dir_gs consecutive frames each
+    int teams;                 // the stages of a frame run on a team of NT / G threads of its own (see pfb_team_barrier)
 };
 
 // the prime-first stage with one (q, column) pair per work item; see lds_stage_prime_first
@@ -1004,6 +1006,43 @@ __device__ __forceinline__ void pfb_cu_filter_direct(const PfbCuArgs &a, float2 
 
 // TWL: the twiddle table is copied into the LDS (a template parameter, not a run-time choice between an LDS and a
 // global pointer: that would be a flat pointer)
+// A barrier among the waves of ONE team (the NT / G threads that take one frame of the run through its stages).
+// The workgroup's frames are independent from the filter on; s_barrier makes all sixteen waves meet after every
+// stage, in step -- every wave then fights for the LDS and the issue slots at the same time and idles together
+// (1.75 us per radix-8 stage against 1.15 us in four separate workgroups of 256 threads).  gfx950 has
+// no named barriers, so a team counts arrivals in an LDS word: the wave's own LDS traffic has completed
+// (release fence = s_waitcnt lgkmcnt(0)), one lane adds 1, everyone polls until all `waves` arrivals of this round
+// are in.  The count only grows (round r ends at r * waves), nothing is reset, nobody can be left behind.  The poll
+// is bounded: a team that never completes (it cannot, short of a bug) falls through instead of hanging the chip.
+__device__ __forceinline__ void pfb_team_barrier(unsigned *ctr, unsigned &target, unsigned waves, int tid) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    target += waves;
+    if ((tid & 63) == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (int guard = 0; guard < (1 << 20); ++guard) {
+        if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= target) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// one stage of one frame on a team (the radices of plans without a matrix-core stage)
+__device__ __forceinline__ void pfb_team_stage(int R, const float2 *src, float2 *dst, int n, int p, int st, int stw, unsigned mt,
+                                               unsigned mp, const float2 *tw, int ttid, int TS) {
+    switch (R) {
+        case 2: lds_stage<2>(src, dst, n, p, st, stw, mt, mp, tw, 1, ttid, TS); break;
+        case 3: lds_stage<3>(src, dst, n, p, st, stw, mt, mp, tw, 1, ttid, TS); break;
+        case 4: lds_stage<4>(src, dst, n, p, st, stw, mt, mp, tw, 1, ttid, TS); break;
+        case 5: lds_stage<5>(src, dst, n, p, st, stw, mt, mp, tw, 1, ttid, TS); break;
+        case 6: lds_stage<6>(src, dst, n, p, st, stw, mt, mp, tw, 1, ttid, TS); break;
+        case 7: lds_stage<7>(src, dst, n, p, st, stw, mt, mp, tw, 1, ttid, TS); break;
+        case 8: lds_stage<8>(src, dst, n, p, st, stw, mt, mp, tw, 1, ttid, TS); break;
+        case 10: lds_stage<10>(src, dst, n, p, st, stw, mt, mp, tw, 1, ttid, TS); break;
+        case 11: lds_stage<11>(src, dst, n, p, st, stw, mt, mp, tw, 1, ttid, TS); break;
+        case 13: lds_stage<13>(src, dst, n, p, st, stw, mt, mp, tw, 1, ttid, TS); break;
+        default: lds_stage<16>(src, dst, n, p, st, stw, mt, mp, tw, 1, ttid, TS); break;
+    }
+}
+
 // NT: 1024 threads, one workgroup per compute unit -- or 512, two per unit with half the frames each (the direct
 // filter only: it needs no raw samples in the LDS): two workgroups drift apart, one computes while the other waits
 // at a barrier or for its loads, where the sixteen waves of one workgroup meet at every barrier in step
@@ -1182,11 +1221,43 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) GSDR
             A[fr * len + n + (g - fr * pad)] = mk2(0.f, 0.f);
         }
     }
+    // arrival counters of the teams (behind the bin table: (n + 1) / 2 float2 hold it)
+    unsigned *team_ctr = reinterpret_cast<unsigned *>(sel_l + 2 * ((n + 1) / 2));
+    if (a.teams && tid < G) team_ctr[tid] = 0u;
     __syncthreads();
     fft_stamp(2);
 
-    // ---- 3. the transform of all G frames, stage by stage ----
     const float2 *tw = TWL ? twl : a.tw;
+    if (a.teams) {
+        // ---- 3 + 4 by teams: NT / G threads take one frame through all stages and write its bins ----
+        const int TS = NT / G, fr = tid / TS, ttid = tid - fr * TS;       // (G divides NT: the host only sets `teams` then)
+        const unsigned waves = (unsigned)(TS >> 6);
+        unsigned target = 0;
+        int src_off = fr * len, dst_off = a.b_off + fr * len, p = 1;
+        for (int s = 0; s < a.n_radices; ++s) {
+            const int R = __builtin_amdgcn_readlane(st_radix, s);
+            const unsigned mt = (unsigned)__builtin_amdgcn_readlane(st_mag_t, s), mp = (unsigned)__builtin_amdgcn_readlane(st_mag_p, s);
+            const int st = __builtin_amdgcn_readlane(st_t, s), stw = __builtin_amdgcn_readlane(st_tws, s);
+            pfb_team_stage(R, pfb_lds + src_off, pfb_lds + dst_off, len, p, st, stw, mt, mp, tw, ttid, TS);
+            if (waves > 1) pfb_team_barrier(team_ctr + fr, target, waves, tid);
+            else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            if (s < 2) fft_stamp(3 + s);
+            p *= R;
+            const int t2 = src_off;
+            src_off = dst_off;
+            dst_off = t2;
+        }
+        fft_stamp(5);
+        if (fr < Gw) {
+            const float2 *res = pfb_lds + src_off;
+            float2 *o = a.out + (size_t)(f0 + fr) * a.n_out;
+            for (int u = ttid; u < a.n_out; u += TS) o[u] = res[a.sel ? sel_l[u] : u];
+        }
+        fft_stamp(7);
+        return;
+    }
+
+    // ---- 3. the transform of all G frames, stage by stage ----
     int pp = 1;
     int res_off = pfb_cu_stages<NT>(a, pfb_lds, 0, a.b_off, tw, roots, st_radix, st_mag_t, st_mag_p, st_t, st_tws, tid, 0, 1, pp);
     res_off = pfb_cu_stages<NT>(a, pfb_lds, res_off, res_off == 0 ? a.b_off : 0, tw, roots, st_radix, st_mag_t, st_mag_p, st_t,
@@ -1515,7 +1586,7 @@ static bool pfb_cu_shape(int nfft, int avg, int len, int want, int &G, int &b_of
         bl = (bl + 1) & ~1LL;
         for (twl = len <= kPfbLdsTwMaxN ? 1 : 0; twl >= 0; --twl) {
             // + the bin table (n_out <= nfft ints)
-            const long long total = (al + bl + kPfbLdsMaxPrime + 1 + (twl ? len : 0) + (nfft + 1) / 2) * (long long)sizeof(float2);
+            const long long total = (al + bl + kPfbLdsMaxPrime + 1 + (twl ? len : 0) + (nfft + 1) / 2 + 32) * (long long)sizeof(float2);   // (+ 64 team counters)
             if (total <= max_bytes) {
                 b_off = (int)al;
                 b_len = (int)bl;
@@ -1642,6 +1713,12 @@ static hipError_t launch_pfb_cu(const float2 *carry, int new_0, const float2 *in
         if (!blue && !cu_forced && threads == kPfbCuThreads && !(a.n_radices > 0 && a.radices[0] > 13) &&
             pfb_cu_fill(nfft, avg, len, frames_n, cus) < 0.7)
             return hipSuccess;                             // the frame-per-workgroup kernel fills the chip better
+    }
+    {
+        // teams: the frames of a run go through their stages independently (GSDR_PFB_TEAMS=0: all waves in step)
+        bool plain = !blue && a.n_radices > 0;
+        for (int i = 0; i < a.n_radices; ++i) plain = plain && a.radices[i] <= 16;
+        a.teams = plain && env_teams.get() != 0 && a.G >= 2 && threads % a.G == 0 && (threads / a.G) % 64 == 0;
     }
     a.carry = carry; a.in = in; a.window = window; a.tw = tw; a.sel = sel; a.out = out; a.carry_out = carry_out;
     a.chirp = blue ? blue->d_chirp : nullptr;

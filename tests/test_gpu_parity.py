@@ -887,6 +887,7 @@ PFB_VARIANTS = [
     ({"GSDR_PFB_CU": "1", "GSDR_PFB_CU_NT": "1024"}, "pfb_cu_kernel", "one workgroup of 1024 threads per unit"),
     ({"GSDR_PFB_CU": "1", "GSDR_PFB_CU_NT": "512"},  "pfb_cu_kernel", "two workgroups of 512 threads per unit where the direct filter takes them"),
     ({"GSDR_PFB_RADIX8": "0"},         None,             "radix 4 / 2 stages only"),
+    ({"GSDR_PFB_TEAMS": "0"},          None,             "all waves of the run kernel in step through the stages (no teams)"),
 ]
 PFB_VARIANT_SHAPES = [
     # nfft, avg, L, buffers
@@ -911,7 +912,7 @@ def test_noise_every_kernel_variant(cuda_device, gsdr_lib, oracle_mod, monkeypat
     suite only sees the variant the library picks for a shape."""
     import gpu_sdr_amd as g
     from gpu_sdr_amd import _lib
-    for k in ("GSDR_PFB_CU", "GSDR_PFB_DIRECT", "GSDR_PFB_COL", "GSDR_PFB_CU_NT", "GSDR_PFB_RADIX8"):
+    for k in ("GSDR_PFB_CU", "GSDR_PFB_DIRECT", "GSDR_PFB_COL", "GSDR_PFB_CU_NT", "GSDR_PFB_RADIX8", "GSDR_PFB_TEAMS"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
