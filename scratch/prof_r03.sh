@@ -24,5 +24,7 @@ for WL in ${WLS:-c3 c3flat c2 pfb c4}; do
   timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc3 -- python3 $P > $OUT/pmc3.log 2>&1 || true
   echo "$WL pmc3 done" >> $R/gpurun_out/prof_r03.progress
   timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc4 -- python3 $P > $OUT/pmc4.log 2>&1 || true
+  # gpurun copies at most 64 MiB back: the per-launch trace of a 4 us kernel is 15 MB, its first 30 000 rows do
+  find $OUT $IO -name '*kernel_trace.csv' -size +4M -exec sh -c 'head -n 30000 "$1" > "$1.t" && mv "$1.t" "$1"' _ {} \;
   echo "prof $WL done" | tee -a $R/gpurun_out/prof_r03.progress
 done
