@@ -33,6 +33,8 @@
 //     reference's FIR::_dout carry, cpp/fir.cu:64-69).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "ddc_device.h"
 #include "ddc_kernels.h"
 
@@ -307,6 +309,53 @@ __global__ __launch_bounds__(256) GSDR_NO_PK void mix_small_kernel(
     }
 }
 
+// The same for at most 32 tones (round 3).  mix_small_kernel keeps mix_kernel's unit structure -- K samples per step of
+// the block phasor, a table of K fp32 phasors inside the unit -- and with T = 1, 2 tones that leaves most lanes of
+// a wave without a sample and every sample with ~30 instructions of 64-bit index arithmetic: 14 us per 1 M-sample
+// buffer for one tone, whose 16 MB of traffic are 4 us of HBM time (profiles/r03_mix_rate.log).  Here a lane IS a
+// (sample phase s, tone n) pair, the wave walks S = 64 / T consecutive samples per step, and each lane carries its
+// own phasor: exact at its first sample (integer phase law, ref kernels.cu:66-69, sincos in double), advanced by
+// w_n^S in double from step to step (at most a few dozen steps per wave), rounded to float for the one complex
+// product per output (the reference: double sincospi, float product, kernels.cu:72-83).  One store covers S samples
+// x T tones: 512 contiguous bytes when T == N.
+__global__ __launch_bounds__(256) GSDR_NO_PK void mix_few_kernel(const float2 *__restrict__ x, const unsigned *__restrict__ fmod,
+                                                                 float2 *__restrict__ out, DdcShape sh, int tshift, int steps) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    const int S = 64 >> tshift;
+    const int n = lane & ((1 << tshift) - 1), s = lane >> tshift;
+    const long long total = sh.total;
+    const long long j0 = (long long)wave * steps * S + s;      // this lane's first sample
+    if ((long long)wave * steps * S >= total) return;
+    const unsigned f = fmod[n < sh.N ? n : 0];
+    const unsigned long long s0 = mod_rate(sh.idx0 + (unsigned long long)j0, sh.rate, sh.rate_magic);
+    double Pr, Pi, Wr, Wi;
+    exact_phasor(mod_rate((unsigned long long)f * s0, sh.rate, sh.rate_magic), sh.inv_rate, Pr, Pi);
+    exact_phasor(mod_rate((unsigned long long)f * (unsigned long long)S, sh.rate, sh.rate_magic), sh.inv_rate, Wr, Wi);
+    const float2 *xp = x + j0;
+    float2 *op = out + (size_t)j0 * sh.N + n;
+    const size_t ostep = (size_t)S * sh.N;
+    const bool tone = n < sh.N;
+    long long j = j0;
+#pragma unroll 4
+    for (int i = 0; i < steps; ++i) {
+        if (j < total) {
+            const float2 v = *xp;
+            const float pr = (float)Pr, pi = (float)Pi;
+            float2 o;
+            o.x = v.x * pr - v.y * pi;
+            o.y = v.x * pi + v.y * pr;
+            if (tone) *op = o;
+        }
+        const double t = Pr * Wr - Pi * Wi;
+        Pi = Pr * Wi + Pi * Wr;
+        Pr = t;
+        j += S;
+        xp += S;
+        op += ostep;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
@@ -359,7 +408,28 @@ hipError_t launch_ddc(int F, int K, const DdcLaunch &a, hipStream_t st, hipEvent
     return e;
 }
 
+// up to how many tones mix_few_kernel runs: same box, per 1 M-sample buffer, against mix_small_kernel / mix_kernel:
+// 1 tone 6.8 against 14.3 us, 4: 11.4 / 15.8, 8: 16 / 21, 16: 27 / 32, 32: 68 / 77 - 82, 64: 144 / 110
+// (profiles/r03_mix_rate.log).  GSDR_MIX_FEW=<n> moves the limit (0: the older kernels; read at every call, the
+// tests use it).
+static int mix_few_max() {
+    const char *e = std::getenv("GSDR_MIX_FEW");
+    return e && e[0] ? std::atoi(e) : 32;
+}
+
 hipError_t launch_mix(int K, const DdcLaunch &a, hipStream_t st) {
+    if (a.sh.N <= mix_few_max() && a.sh.TW == 1 && a.sh.total > 0) {
+        // very few tones: a lane per (sample, tone) with a phasor of its own (mix_few_kernel)
+        int tshift = 0;
+        while ((1 << tshift) < a.sh.N) ++tshift;
+        const long long S = 64 >> tshift;
+        const long long all_steps = (a.sh.total + S - 1) / S;
+        long long steps = (all_steps + 8191) / 8192;            // ~8192 waves, at least 8 steps each
+        if (steps < 8) steps = 8;
+        const long long waves = (all_steps + steps - 1) / steps;
+        hipLaunchKernelGGL(mix_few_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a.x, a.fmod, a.out, a.sh, tshift, (int)steps);
+        return hipGetLastError();
+    }
     if (a.sh.N <= 32 && a.sh.TW == 1 && (K == 16 || K == 32)) {
         // few tones: several sample phases per wave (mix_small_kernel); T >= 2 keeps S = 64 / T <= K / ... <= 32
         int tshift = 1;
@@ -386,6 +456,6 @@ hipError_t launch_mix(int K, const DdcLaunch &a, hipStream_t st) {
 }
 
 const char *ddc_kernel_name() { return "ddc_kernel"; }
-const char *mix_kernel_name(int n_tones) { return n_tones <= 32 ? "mix_small_kernel" : "mix_kernel"; }
+const char *mix_kernel_name(int n_tones) { return n_tones <= mix_few_max() ? "mix_few_kernel" : n_tones <= 32 ? "mix_small_kernel" : "mix_kernel"; }
 
 }  // namespace gsdr

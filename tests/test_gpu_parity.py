@@ -613,14 +613,20 @@ def test_direct_streaming_equals_one_long_buffer(cuda_device, gsdr_lib, engine):
     assert rel_err_per_tone(yb, ya).max() <= 2e-6
 
 
-def test_direct_undecimated(cuda_device, gsdr_lib, oracle_mod):
+@pytest.mark.parametrize("few", ["default", "older_kernels"])
+def test_direct_undecimated(cuda_device, gsdr_lib, oracle_mod, monkeypatch, few):
     rng = np.random.default_rng(6)
-    # (at most 32 tones: mix_small_kernel, several sample phases per wave; more: a lane per tone)
+    # (at most 32 tones: mix_few_kernel, a lane per (sample, tone) with its own phasor; more: a lane per tone.
+    #  GSDR_MIX_FEW=0: round 2's kernels -- at most 32 tones mix_small_kernel, several sample phases per wave)
+    if few == "older_kernels":
+        monkeypatch.setenv("GSDR_MIX_FEW", "0")
+    few_max = 32 if few == "default" else 0
     for N, rate, L in [(3, 1000, 1000), (70, 1_000_000, 5000), (5, 200_000_000, 4099), (1, 1000, 777), (2, 10_000, 2048),
-                       (8, 200_000_000, 100_003), (17, 1_000_000, 9000), (32, 1_000_000, 4096), (33, 1_000_000, 4096)]:
+                       (8, 200_000_000, 100_003), (17, 1_000_000, 9000), (32, 1_000_000, 4096), (33, 1_000_000, 4096),
+                       (1, 200_000_000, 1_000_000), (4, 200_000_000, 999_983), (7, 123_456_789, 300_001), (9, 1_000_000, 5000)]:
         freq = rng.integers(-rate // 2 + 1, rate // 2, size=N)
         dem = make_direct(freq, rate, 0, 4, L)
-        assert dem.kernel_name == ("mix_small_kernel" if N <= 32 else "mix_kernel")
+        assert dem.kernel_name == ("mix_few_kernel" if N <= few_max else "mix_small_kernel" if N <= 32 else "mix_kernel")
         ref = oracle_mod.Direct(freq, rate, 0, 4, L)
         for c in range(3):
             x = crandn(rng, L)
