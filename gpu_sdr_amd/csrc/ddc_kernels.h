@@ -51,6 +51,7 @@ struct DdcLaunch {
     DdcShape sh;
     unsigned lds_bytes;     // dynamic LDS per workgroup (occupancy cap, see launch_flat_fk)
     bool pipe;              // use ddc_flat_kernel (F <= 4, phasor table length K in {12,16,20})
+    bool few;               // use ddc_few_kernel (a wave per (chunk, tone): a handful of tones at a long decimation)
 };
 
 // F = tap phases (pf_average, 1..8), K = phasor-table length (16 or 32; 12/16/20
@@ -58,6 +59,7 @@ struct DdcLaunch {
 // Enqueues ddc_kernel<F,K> and, when F > 1, ddc_fixup.  `stop` (may be null)
 // is recorded right after ddc_kernel, before the fixup.
 hipError_t launch_ddc(int F, int K, const DdcLaunch &a, hipStream_t st, hipEvent_t stop);
+const char *ddc_few_kernel_name();
 // Undecimated DIRECT (decim == 0).
 hipError_t launch_mix(int K, const DdcLaunch &a, hipStream_t st);
 

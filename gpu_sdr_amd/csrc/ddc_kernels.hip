@@ -162,6 +162,109 @@ __global__ __launch_bounds__(256) GSDR_NO_PK void ddc_kernel(
     }
 }
 
+// Sum over the 64 lanes of a wave with DPP row operations; the total arrives in lane 63 (see chirp_kernels.hip).
+__device__ __forceinline__ float ddc_wave_sum63(float v) {
+    int x = __float_as_int(v);
+#define GSDR_DPP_ADD(ctrl, row_mask)                                                                    \
+    x = __float_as_int(__int_as_float(x) +                                                              \
+                       __int_as_float(__builtin_amdgcn_update_dpp(0, x, ctrl, row_mask, 0xf, false)))
+    GSDR_DPP_ADD(0xB1, 0xf);    // quad_perm [1,0,3,2]
+    GSDR_DPP_ADD(0x4E, 0xf);    // quad_perm [2,3,0,1]
+    GSDR_DPP_ADD(0x141, 0xf);   // row_half_mirror
+    GSDR_DPP_ADD(0x140, 0xf);   // row_mirror: every lane holds the sum of its row of 16
+    GSDR_DPP_ADD(0x142, 0xa);   // row_bcast:15 into rows 1 and 3
+    GSDR_DPP_ADD(0x143, 0xc);   // row_bcast:31 into rows 2 and 3
+#undef GSDR_DPP_ADD
+    return __int_as_float(x);
+}
+
+// A handful of tones at a long decimation (round 3).  Every other DDC kernel gives a tone to a lane (or to a matrix
+// column) and walks the samples of a block in sequence: with 16 tones at decim 1000 a launch is as long as ONE
+// wave's (one workgroup's) walk through its blocks -- 72 us per 1 M-sample buffer on the matrix cores, 150 on the
+// packed-FP32 kernel, for 0.35 GFLOP (profiles/r03_shape_sweep.log).  Here a WAVE is a (chunk, tone) pair and its 64
+// lanes split the samples of a block: lane l takes t = l, l + 64, ...; its phasor is exact at t = l of every block
+// (integer phase law, ref kernels.cu:66-69; sincos in double) and advances by w_n^64 in double; the F tap-phase sums
+// of a block (ref fir.cu:48-61) are reduced over the wave with DPP adds.  Same chunk protocol as ddc_kernel: partial
+// heads into `out`, F - 1 partial tails into `tails`, ddc_fixup adds them, the last chunk's tail is the carry.
+template <int F>
+__global__ __launch_bounds__(256) GSDR_NO_PK void ddc_few_kernel(
+    const float2 *__restrict__ x, const float *__restrict__ taps_t, const unsigned *__restrict__ fmod,
+    float2 *__restrict__ out, float2 *__restrict__ tails, float2 *__restrict__ carry_out, DdcShape sh) {
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wave = (int)blockIdx.x * 4 + wid;
+    const int M = sh.M, N = sh.N, Npad = sh.Npad;
+    if (wave >= N * sh.nch) return;
+    const int chunk = wave / N, n = wave - chunk * N;          // wave-uniform
+    const unsigned f = fmod[n];
+    double Wr, Wi;
+    exact_phasor(mod_rate((unsigned long long)f * 64ull, sh.rate, sh.rate_magic), sh.inv_rate, Wr, Wi);
+    const int b0 = chunk_begin(chunk, sh);
+    const int b1 = chunk_begin(chunk + 1, sh);
+    float2 A[F];
+#pragma unroll
+    for (int k = 0; k < F; ++k) { A[k].x = 0.f; A[k].y = 0.f; }
+    for (int b = b0; b < b1; ++b) {
+        const float2 *__restrict__ xb = x + (size_t)b * M;
+        // ref: kernels.cu:66-69  ii=(j+idx)%rate; phase=(tf*ii)%rate, at this lane's first sample of the block
+        const unsigned long long s0 =
+            mod_rate(sh.idx0 + (unsigned long long)b * sh.m_mod_rate + (unsigned long long)lane, sh.rate, sh.rate_magic);
+        double Pr, Pi;
+        exact_phasor(mod_rate((unsigned long long)f * s0, sh.rate, sh.rate_magic), sh.inv_rate, Pr, Pi);
+        float2 S[F];
+#pragma unroll
+        for (int j = 0; j < F; ++j) { S[j].x = 0.f; S[j].y = 0.f; }
+        // U steps at a time, their loads first (clamped, not branched on): with the load inside the step that uses it a
+        // wave paid a memory round trip per 64 samples -- 48 in a row at decim 1000, 31 us per buffer for ONE tone
+        constexpr int U = 8;
+        for (int t0 = lane; t0 < M; t0 += 64 * U) {
+            float2 v[U];
+            float h[U][F];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = t0 + 64 * u, tc = t < M ? t : M - 1;
+                v[u] = xb[tc];
+                const float *__restrict__ hp = taps_t + (size_t)tc * F;
+#pragma unroll
+                for (int j = 0; j < F; ++j) h[u][j] = hp[j];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (t0 + 64 * u < M) {
+                    const float pr = (float)Pr, pi = (float)Pi;
+                    const float ur = v[u].x * pr - v[u].y * pi, ui = v[u].x * pi + v[u].y * pr;
+#pragma unroll
+                    for (int j = 0; j < F; ++j) {
+                        S[j].x = fmaf(h[u][j], ur, S[j].x);
+                        S[j].y = fmaf(h[u][j], ui, S[j].y);
+                    }
+                }
+                const double tt = Pr * Wr - Pi * Wi;
+                Pi = Pr * Wi + Pi * Wr;
+                Pr = tt;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < F; ++j) {
+            // tap phase j of block b feeds output G = b + F-1-j  (fir.cu:56-61); the sum of the wave is in lane 63
+            A[F - 1 - j].x += ddc_wave_sum63(S[j].x);
+            A[F - 1 - j].y += ddc_wave_sum63(S[j].y);
+        }
+        if (b >= sh.g_off && lane == 63) out[(size_t)(b - sh.g_off) * N + n] = A[0];
+#pragma unroll
+        for (int k = 0; k + 1 < F; ++k) A[k] = A[k + 1];
+        A[F - 1].x = 0.f;
+        A[F - 1].y = 0.f;
+    }
+    if (F > 1 && lane == 63) {
+        float2 *dst = (chunk == sh.nch - 1) ? carry_out : tails + (size_t)(chunk + 1) * (F - 1) * Npad;
+        if (dst) {
+#pragma unroll
+            for (int k = 0; k + 1 < F; ++k) dst[(size_t)k * Npad + n] = A[k];
+        }
+    }
+}
+
 // Adds the tail partial sums of chunk c-1 (or the stream carry, c == 0) to the
 // head outputs of chunk c.  Tiny: nch*(F-1)*Npad threads.
 __global__ GSDR_NO_PK void ddc_fixup(float2 *__restrict__ out, const float2 *__restrict__ tails,
@@ -383,13 +486,37 @@ static hipError_t launch_ddc_k(int F, const DdcLaunch &a, hipStream_t st) {
     }
 }
 
+template <int F>
+static hipError_t launch_ddc_few_f(const DdcLaunch &a, hipStream_t st) {
+    const long long waves = (long long)a.sh.N * a.sh.nch;
+    hipLaunchKernelGGL((ddc_few_kernel<F>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a.x, a.taps_t, a.fmod, a.out,
+                       a.tails, a.carry_out, a.sh);
+    return hipGetLastError();
+}
+
+static hipError_t launch_ddc_few(int F, const DdcLaunch &a, hipStream_t st) {
+    if (a.sh.TW != 1) return hipErrorInvalidValue;          // (tones are waves here, not lanes: one table row)
+    switch (F) {
+        case 1: return launch_ddc_few_f<1>(a, st);
+        case 2: return launch_ddc_few_f<2>(a, st);
+        case 3: return launch_ddc_few_f<3>(a, st);
+        case 4: return launch_ddc_few_f<4>(a, st);
+        case 5: return launch_ddc_few_f<5>(a, st);
+        case 6: return launch_ddc_few_f<6>(a, st);
+        case 7: return launch_ddc_few_f<7>(a, st);
+        case 8: return launch_ddc_few_f<8>(a, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
 hipError_t launch_ddc(int F, int K, const DdcLaunch &a, hipStream_t st, hipEvent_t stop) {
     // shapes are checked on the host: a kernel that writes past `tails` faults the GPU
     if (a.sh.nch < 1 || a.sh.nblk < 1 || a.sh.TW < 1 || (F > 1 && a.sh.nch > a.tails_nch) ||
         (F > 1 && a.sh.nch > 1 && a.sh.nblk / a.sh.nch < F - 1))
         return hipErrorInvalidValue;
     hipError_t e;
-    if (a.pipe) e = launch_ddc_flat_main(F, K, a, st);
+    if (a.few) e = launch_ddc_few(F, a, st);
+    else if (a.pipe) e = launch_ddc_flat_main(F, K, a, st);
     else if (K == 16) e = launch_ddc_k<16>(F, a, st);
     else if (K == 32) e = launch_ddc_k<32>(F, a, st);
     else return hipErrorInvalidValue;
@@ -456,6 +583,7 @@ hipError_t launch_mix(int K, const DdcLaunch &a, hipStream_t st) {
 }
 
 const char *ddc_kernel_name() { return "ddc_kernel"; }
+const char *ddc_few_kernel_name() { return "ddc_few_kernel"; }
 const char *mix_kernel_name(int n_tones) { return n_tones <= mix_few_max() ? "mix_few_kernel" : n_tones <= 32 ? "mix_small_kernel" : "mix_kernel"; }
 
 }  // namespace gsdr

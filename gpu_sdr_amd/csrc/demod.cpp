@@ -100,6 +100,7 @@ struct gsdr_demod {
     int parity = 0;
     // ---- DDC on the matrix cores (ddc_mfma.hip) ----
     bool mfma = false;
+    bool few = false;                  // DIRECT: a handful of tones at a long decimation run ddc_few_kernel (a wave per chunk and tone)
     int mf_TT = 1, mf_PK = 32, mf_W = 4;   // tone tiles per wave, phasor block, waves per workgroup
     gsdr::MfmaKernel mf_kind = gsdr::MfmaKernel::AsmRing;
     gsdr::MfmaShape mf{};              // fields that do not change between calls
@@ -768,6 +769,7 @@ int enqueue_direct(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t st)
     a.taps_t = h->d_taps_t;
     a.taps_p = h->d_taps_p;
     a.pipe = h->pipe && h->decim > 0 && h->L >= 4;
+    a.few = h->few;
     a.lds_bytes = h->lds_bytes;
     a.sh.prefetch = h->prefetch;
     a.btab = h->d_btab;
@@ -1109,7 +1111,14 @@ gsdr_demod *gsdr_demod_create(const gsdr_param_c *p) {
                 }
                 // (rows read whole 32-sample phasor blocks: the padding behind a window must stay
                 //  within the next block, or middle rows would read past the buffer)
-                if (!rc && env_int("GSDR_DDC_MFMA", 1) != 0 && h->L / M >= F - 1 && h->L >= 4 && F <= 33 &&
+                // A handful of tones at a long decimation: every engine below walks a block's samples in sequence per
+                // tone lane / matrix column, and a launch is as long as one workgroup's walk (72 us per 1 M-sample
+                // buffer for 1 ... 256 tones at decim 1000).  ddc_few_kernel splits the block over the lanes of a wave
+                // per (chunk, tone): 16 tones at decim 1000 in 15 us (profiles/r03_shape_sweep.log).  GSDR_DDC_FEW=0: off.
+                h->few = !rc && env_int("GSDR_DDC_MFMA", 1) != 0 && env_int("GSDR_DDC_FEW", 1) != 0 && !h->pipe &&
+                         M >= 512 && h->N <= 32 && h->TW == 1;
+                if (h->few) h->kernel_name = gsdr::ddc_few_kernel_name();
+                if (!rc && !h->few && env_int("GSDR_DDC_MFMA", 1) != 0 && h->L / M >= F - 1 && h->L >= 4 && F <= 33 &&
                     (M * F + 31) / 32 * 32 - M * F <= M)
                     rc = setup_mfma(h, /*direct=*/true, tone);
                 if (!rc && !h->mfma) rc = autotune_chunks(h, (int)(h->L / M));

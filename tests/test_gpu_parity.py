@@ -637,6 +637,33 @@ def test_direct_undecimated(cuda_device, gsdr_lib, oracle_mod, monkeypatch, few)
         dem.close()
 
 
+@pytest.mark.parametrize("N,M,F,L,nbuf", [(1, 1000, 4, 100_000, 4), (5, 512, 3, 102_400, 3), (16, 1000, 4, 1_000_000, 3),
+                                          (32, 2000, 2, 200_000, 3), (3, 777, 8, 77_700, 4), (2, 4096, 4, 8192, 6),
+                                          (7, 1000, 1, 50_000, 3)], ids=lambda v: str(v))
+@pytest.mark.parametrize("few", ["few", "GSDR_DDC_FEW=0"])
+def test_direct_few_tones_long_decimation(cuda_device, gsdr_lib, oracle_mod, monkeypatch, N, M, F, L, nbuf, few):
+    """A handful of tones at a decimation of 512 and more: ddc_few_kernel (a wave per (chunk, tone), the lanes split
+    the samples of a block) against the oracle, and the engine the library would take otherwise on the same buffers.
+    The last shape but one has blocks longer than half a buffer (two blocks per call, F - 1 = 3 of carry)."""
+    if few != "few":
+        monkeypatch.setenv("GSDR_DDC_FEW", "0")
+    rate = 200_000_000
+    rng = np.random.default_rng(7000 + N * M)
+    freq = rng.choice(np.arange(-rate // 2 + 1, rate // 2), size=N, replace=False)
+    dem = make_direct(freq, rate, M, F, L)
+    assert (dem.kernel_name == "ddc_few_kernel") == (few == "few"), dem.kernel_name
+    ref = oracle_mod.Direct(freq, rate, M, F, L)
+    for c in range(nbuf):
+        x = crandn(rng, L) * (1.0, 30.0, 0.01, 1.0, 5.0, 1.0)[c % 6]
+        y = run_device(dem, x, cuda_device) if c != 1 else run_host(dem, x)
+        yr = ref.process(x)
+        assert y.size == yr.size == N * (L // M)
+        e = rel_err_per_tone(y.reshape(-1, N), yr).max()
+        record_margin(float(e), "worst tone")
+        assert e <= TOL
+    dem.close()
+
+
 def test_direct_pure_tones_demodulate_to_their_phasors(cuda_device, gsdr_lib, engine):
     """Closed form, no oracle: a comb demodulates to a_k e^{i phi_k} (DC gain of h is 1)."""
     from gpu_sdr_amd.source import host_tones
