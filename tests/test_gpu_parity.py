@@ -86,6 +86,7 @@ def engine(request, monkeypatch):
             monkeypatch.delenv(k)
         return request.param
     monkeypatch.setenv("GSDR_TONES_FFT", "0")
+    monkeypatch.setenv("GSDR_DDC_FEW", "0")          # (the forced engine, also where ddc_few_kernel would take the shape)
     monkeypatch.setenv("GSDR_DDC_MFMA", "0" if request.param == "flat" else "1")
     monkeypatch.setenv("GSDR_MFMA_ASM", {"mfma16": "4", "mfma16w8": "5", "mfma16p": "4"}.get(request.param, "2"))
     monkeypatch.setenv("GSDR_MFMA_PREC", "1" if request.param == "mfma16p" else "0")
@@ -98,6 +99,7 @@ def mfma_engine(request, monkeypatch):
     """Matrix-core DDC: round 1's loop on the 32x32x16 MFMA / the ring loop on the 16x16x32 shape /
     its eight-wave build / its pre-converted-operand build."""
     monkeypatch.setenv("GSDR_DDC_MFMA", "1")
+    monkeypatch.setenv("GSDR_DDC_FEW", "0")
     monkeypatch.setenv("GSDR_TONES_FFT", "0")
     monkeypatch.setenv("GSDR_MFMA_ASM", {"x16": "4", "x16w8": "5", "x16p": "4"}.get(request.param, "2"))
     monkeypatch.setenv("GSDR_MFMA_PREC", "1" if request.param == "x16p" else "0")
@@ -525,14 +527,15 @@ def test_direct_isolated_spike(cuda_device, gsdr_lib, oracle_mod, monkeypatch, i
 
 
 EXTREME_ENGINES = {
-    # name: (GSDR_DDC_MFMA, GSDR_DDC_PIPE, GSDR_MFMA_ASM, GSDR_MFMA_PREC)
-    "flat": ("0", "1", "4", "0"),        # packed-FP32 VALU kernel (north_star's arithmetic)
-    "generic": ("0", "0", "4", "0"),     # compiler-scheduled FP32 VALU kernel
-    "mfma16": ("1", "1", "4", "0"),      # the default matrix-core loop
-    "mfma16w8": ("1", "1", "5", "0"),
-    "mfma16p": ("1", "1", "4", "1"),
-    "mfma32": ("1", "1", "2", "0"),
-    "mfmacxx": ("1", "1", "0", "0"),
+    # name: (GSDR_DDC_MFMA, GSDR_DDC_PIPE, GSDR_MFMA_ASM, GSDR_MFMA_PREC, GSDR_DDC_FEW)
+    "flat": ("0", "1", "4", "0", "0"),        # packed-FP32 VALU kernel (north_star's arithmetic)
+    "generic": ("0", "0", "4", "0", "0"),     # compiler-scheduled FP32 VALU kernel
+    "mfma16": ("1", "1", "4", "0", "0"),      # the default matrix-core loop
+    "mfma16w8": ("1", "1", "5", "0", "0"),
+    "mfma16p": ("1", "1", "4", "1", "0"),
+    "mfma32": ("1", "1", "2", "0", "0"),
+    "mfmacxx": ("1", "1", "0", "0", "0"),
+    "few": ("1", "1", "4", "0", "1"),         # the library as shipped: ddc_few_kernel where it takes the shape (M1000), else mfma16
 }
 
 
@@ -553,15 +556,19 @@ def test_direct_extreme_and_nonfinite_samples(cuda_device, gsdr_lib, oracle_mod,
     tail of the previous rows' windows (M*F = 360 is not a whole number of 32-sample blocks), which must not
     let it through either (0 * Inf)."""
     N, rate, M, F, L = shape
-    mf, pipe, asm, prec = EXTREME_ENGINES[impl]
+    mf, pipe, asm, prec, few = EXTREME_ENGINES[impl]
     monkeypatch.setenv("GSDR_DDC_MFMA", mf)
     monkeypatch.setenv("GSDR_DDC_PIPE", pipe)
     monkeypatch.setenv("GSDR_MFMA_ASM", asm)
     monkeypatch.setenv("GSDR_MFMA_PREC", prec)
+    monkeypatch.setenv("GSDR_DDC_FEW", few)
     from gpu_sdr_amd.source import host_tones, tone_comb
     freq, ampl, phase = tone_comb(N, rate, seed=77)
     dem = make_direct(freq, rate, M, F, L)
-    assert dem.kernel_name.startswith("ddc_mfma") == (mf == "1"), dem.kernel_name
+    if few == "1" and M >= 512 and N <= 32:
+        assert dem.kernel_name == "ddc_few_kernel"
+    else:
+        assert dem.kernel_name.startswith("ddc_mfma") == (mf == "1"), dem.kernel_name
     ref = oracle_mod.Direct(freq, rate, M, F, L)
     at = (L // M // 2) * M + 3
     rows = np.arange(L // M)
