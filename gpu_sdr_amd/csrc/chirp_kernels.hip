@@ -12,6 +12,8 @@
 // HBM-bound: 8 B read per sample, 8/ppt B written.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "ddc_kernels.h"
 #include "ddc_device.h"
 
@@ -260,6 +262,98 @@ __global__ __launch_bounds__(256) GSDR_NO_PK void chirp_lockin_kernel(
     if (lane == 63) out[v] = mk2c(sx, sy);
 }
 
+// Many samples per point (round 3).  chirp_lockin_kernel gives a point to ONE wave: right for the benchmark's 200
+// samples per point, but a VNA scan of a few hundred points over seconds has 1e4 ... 1e6 of them, and a 1 M-sample
+// buffer then holds ten points, or one, or none -- ten waves, or one, walked the whole buffer (ppt 1e5: 162 us per
+// buffer, ppt 1e6: 1.5 ms, profiles/r03_chirp_sweep.log).  Here the stretches of a point -- `decim` steps of
+// ceil(len / 256) stretches each -- are dealt to `parts` waves in contiguous runs; every wave leaves the sum of its
+// run in `partial[point * parts + part]`, chirp_lockin_sum_kernel adds a point's partial sums in order (no atomics:
+// the result does not depend on which wave finishes first).  Same arithmetic per sample as chirp_lockin_kernel.
+__global__ __launch_bounds__(256) GSDR_NO_PK void chirp_lockin_split_kernel(
+    const float2 *__restrict__ carry, int carry_len, const float2 *__restrict__ in,
+    const float *__restrict__ profile, int ppt, int decim, int valid, int parts, int per_part,
+    float2 *__restrict__ partial, unsigned long long index0, ChirpShape cs) {
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wave = (int)blockIdx.x * 4 + wid;
+    if (wave >= valid * parts) return;
+    const int v = wave / parts, part = wave - v * parts;     // wave-uniform
+    const unsigned len = (unsigned)cs.length, steps = (unsigned)cs.num_steps;
+    const unsigned nst = (len + 255u) / 256u, total = (unsigned)decim * nst;
+    const unsigned q0 = (unsigned)part * (unsigned)per_part;
+    const unsigned q1 = q0 + (unsigned)per_part < total ? q0 + (unsigned)per_part : total;
+    float sx = 0.f, sy = 0.f;
+    if (q0 < q1) {
+        const unsigned base = (unsigned)v * (unsigned)ppt;  // position in the logical stage [carry | in]
+        unsigned d = q0 / nst, r0 = (q0 - d * nst) * 256u;
+        ChirpStretch cur, nxt;
+        load_stretch(cur, carry, carry_len, in, profile + (size_t)d * len, base + d * len, r0, len, lane);
+        asm volatile("" ::: "memory");                      // the loads stay in front of the divisions
+        const unsigned e0 = wrap_index(index0, base, cs);   // a multiple of len
+        unsigned fi = (e0 / len + d) % steps;
+        bool new_step = true;
+        unsigned A = 0, K = 0;
+        float sd = 0.f, cd = 1.f;
+        for (unsigned q = q0; q < q1; ++q) {
+            if (new_step) {
+                step_coeffs(fi, cs, A, K);
+                sincos_index((int)(64u * A), sd, cd);
+                new_step = false;
+            }
+            unsigned nd = d, nr0 = r0 + 256u;
+            if (nr0 >= len) {
+                nd = d + 1u;
+                nr0 = 0u;
+            }
+            if (q + 1u < q1)
+                load_stretch(nxt, carry, carry_len, in, profile + (size_t)nd * len, base + nd * len, nr0, len, lane);
+            float sn, cn;
+            sincos_index((int)(K + (r0 + (unsigned)lane) * A), sn, cn);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned r = r0 + (unsigned)(i * 64 + lane);
+                const float2 smp = cur.smp[i];
+                const float chx = sn, chy = -cn;     // chirp = (sinpi, -cospi); in * conj(chirp): demod_one()
+                const float dx = chx * smp.x + chy * smp.y, dy = chx * smp.y - chy * smp.x;
+                const float w = r < len ? cur.w[i] : 0.f;
+                sx = fmaf(dx, w, sx);
+                sy = fmaf(dy, w, sy);
+                const float s2 = fmaf(sn, cd, cn * sd), c2 = fmaf(cn, cd, -(sn * sd));
+                sn = s2;
+                cn = c2;
+            }
+            cur = nxt;
+            if (nd != d) {
+                d = nd;
+                fi = fi + 1u == steps ? 0u : fi + 1u;
+                new_step = true;
+            }
+            r0 = nr0;
+        }
+    }
+    sx = wave_sum_to_lane63(sx);
+    sy = wave_sum_to_lane63(sy);
+    if (lane == 63) partial[wave] = mk2c(sx, sy);
+}
+
+// a wave per point: lane l adds the partial sums l, l + 64, ... in order, the wave adds its lanes (a fixed tree)
+__global__ __launch_bounds__(256) GSDR_NO_PK void chirp_lockin_sum_kernel(const float2 *__restrict__ partial, int valid, int parts,
+                                                                          float2 *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int v = (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (v >= valid) return;
+    const float2 *__restrict__ pp = partial + (size_t)v * parts;
+    float sx = 0.f, sy = 0.f;
+    for (int p = lane; p < parts; p += 64) {
+        const float2 t = pp[p];
+        sx += t.x;
+        sy += t.y;
+    }
+    sx = wave_sum_to_lane63(sx);
+    sy = wave_sum_to_lane63(sy);
+    if (lane == 63) out[v] = mk2c(sx, sy);
+}
+
 // Undecimated demodulation: 4 consecutive runs of 64 samples per wave; the step
 // index of a sample is the wave's base step plus a small quotient.
 __global__ __launch_bounds__(256) GSDR_NO_PK void chirp_demod_kernel(const float2 *__restrict__ in,
@@ -312,11 +406,31 @@ hipError_t launch_chirp_demod(const float2 *in, float2 *out, long long n,
 
 hipError_t launch_chirp_lockin(const float2 *carry, int carry_len, const float2 *in,
                                const float *profile, int ppt, int valid, float2 *out,
-                               unsigned long long index0, const ChirpShape &cs, hipStream_t st) {
+                               unsigned long long index0, const ChirpShape &cs, hipStream_t st,
+                               float2 *partial, int partial_cap) {
     if (valid <= 0) return hipSuccess;
     // the fast kernel needs windows made of whole steps that start on a step boundary:
     // true for every window the demodulator forms (ppt = length*decim, see enqueue_chirp)
-    if (chirp_fits_32(cs) && ppt % (int)cs.length == 0 && index0 % cs.length == 0)
+    const bool fast = chirp_fits_32(cs) && ppt % (int)cs.length == 0 && index0 % cs.length == 0;
+    if (fast && partial && valid <= 512) {
+        // few points with many samples each: deal a point's stretches to several waves (GSDR_CHIRP_SPLIT=0: never)
+        const char *e = std::getenv("GSDR_CHIRP_SPLIT");
+        const long long decim = ppt / (long long)cs.length, nst = ((long long)cs.length + 255) / 256, total = decim * nst;
+        long long parts = (4096 + valid - 1) / valid;            // ~4096 waves in the launch
+        if (parts > total / 4) parts = total / 4;                // at least four stretches per wave
+        if (parts > partial_cap / valid) parts = partial_cap / valid;
+        if (!(e && e[0] == '0') && parts >= 2 && total >= 16 && total < 0x7fffffffLL) {
+            const long long per_part = (total + parts - 1) / parts;
+            parts = (total + per_part - 1) / per_part;
+            const long long waves = (long long)valid * parts;
+            hipLaunchKernelGGL(chirp_lockin_split_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, carry, carry_len, in,
+                               profile, ppt, (int)decim, valid, (int)parts, (int)per_part, partial, index0, cs);
+            hipLaunchKernelGGL(chirp_lockin_sum_kernel, dim3((unsigned)((valid + 3) / 4)), dim3(256), 0, st, partial, valid,
+                               (int)parts, out);
+            return hipGetLastError();
+        }
+    }
+    if (fast)
         hipLaunchKernelGGL(chirp_lockin_kernel, dim3((unsigned)((valid + 3) / 4)), dim3(256), 0, st,
                            carry, carry_len, in, profile, ppt, ppt / (int)cs.length, valid, out, index0, cs);
     else

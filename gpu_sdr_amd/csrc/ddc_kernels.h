@@ -209,7 +209,8 @@ hipError_t launch_chirp_demod(const float2 *in, float2 *out, long long n,
 // stage is [carry (carry_len samples) | in]; index0 is the chirp index of stage[0].
 hipError_t launch_chirp_lockin(const float2 *carry, int carry_len, const float2 *in,
                                const float *profile, int ppt, int valid, float2 *out,
-                               unsigned long long index0, const ChirpShape &cs, hipStream_t st);
+                               unsigned long long index0, const ChirpShape &cs, hipStream_t st,
+                               float2 *partial = nullptr, int partial_cap = 0);   // partial sums of split points (may be null)
 hipError_t launch_warm(hipStream_t st);
 // TX tone comb: out[s] = sum_k q0[k] w_k^(start + s), s < n; fmod = f mod rate, btab[k][64] = w_k^lo,
 // ctab[k][16] = w_k^(64 j), w_k = e^(+2 pi i f_k / rate) (ref: tone_gen, cpp/kernels.cu:589-684)

@@ -38,6 +38,7 @@ constexpr int kMaxEvents = 8192;   // profiling ring
 // Pipelined entries: compute streams that consecutive DIRECT calls go to in turn, and the
 // sets of staging buffers / scale slots that keeps the calls in flight apart (pipeline_compute)
 constexpr int kPipeStreams = 3;
+constexpr int kChirpPartials = 16384;    // float2 slots for the partial sums of split chirp points (chirp_lockin_split_kernel)
 constexpr int kStageSets = kPipeStreams + 1;
 constexpr int kScaleSlots = kPipeStreams + 2;
 
@@ -176,6 +177,7 @@ struct gsdr_demod {
     int ppt = 0;
     gsdr_vna_helper vh{};
     float *d_profile = nullptr;
+    float2 *d_chirp_part = nullptr;    // partial sums of chirp_lockin_split_kernel (kChirpPartials float2)
     float2 *d_ccarry[2] = {nullptr, nullptr};
     int cparity = 0;
     int carry_len = 0;                 // spare_size (ref :54,:369)
@@ -971,7 +973,8 @@ int enqueue_chirp(gsdr_demod *h, const float2 *in, float2 *out, hipStream_t st) 
             h->cs.period;
         if (record_begin(h, st, &stop)) return -1;
         HIPCHK(h, gsdr::launch_chirp_lockin(h->d_ccarry[h->cparity], h->carry_len, in,
-                                            h->d_profile, h->ppt, valid, out, idx0, h->cs, st));
+                                            h->d_profile, h->ppt, valid, out, idx0, h->cs, st, h->d_chirp_part,
+                                            h->d_chirp_part ? kChirpPartials : 0));
         if (stop) HIPCHK(h, hipEventRecord(stop, st));
         // :369-380 the reference keeps the last new0 DEMODULATED samples; we
         // keep the same raw samples and re-demodulate them next call.
@@ -1286,7 +1289,8 @@ gsdr_demod *gsdr_demod_create(const gsdr_param_c *p) {
                 h->kernel_name = gsdr::chirp_lockin_kernel_name();
                 if (upload(&h->d_profile, h->window) != hipSuccess ||
                     dev_alloc(&h->d_ccarry[0], (size_t)h->ppt) != hipSuccess ||
-                    dev_alloc(&h->d_ccarry[1], (size_t)h->ppt) != hipSuccess) {
+                    dev_alloc(&h->d_ccarry[1], (size_t)h->ppt) != hipSuccess ||
+                    dev_alloc(&h->d_chirp_part, (size_t)kChirpPartials) != hipSuccess) {
                     h->err = "chirp allocation failed";
                     rc = -1;
                 }
@@ -1658,6 +1662,7 @@ void gsdr_demod_close(gsdr_demod *h) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
     }
+    if (h->d_chirp_part) (void)hipFree(h->d_chirp_part);
     void *ptrs[] = {h->d_in,      h->d_out,     h->d_taps_t,   h->d_taps_p,   h->d_stage,    h->d_btab,     h->d_wk,
                     h->d_wrem,    h->d_fmod,    h->d_tails,    h->d_carry[0], h->d_carry[1],
                     h->d_profile, h->d_ccarry[0], h->d_ccarry[1],

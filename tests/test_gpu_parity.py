@@ -1036,6 +1036,12 @@ CHIRP_CASES = [
     (1_000_000, -400_000, 400_000, 10, 1e-5, 3, 1000, 3),               # length 1, ppt 3 < 64 lanes
     (200_000_000, -80_000_000, 80_000_000, 1000, 3e-3, 3, 50_000, 4),   # length 600, ppt 1800: three 256-sample
                                                                         # stretches per step, three steps per point
+    # many samples per point, few points per buffer (a VNA scan): chirp_lockin_split_kernel deals a point's
+    # stretches to several waves and chirp_lockin_sum_kernel adds their partial sums
+    (200_000_000, -100_000_000, 100_000_000, 2000, 1.0, 1, 250_000, 4),      # ppt 100 000: 2.5 points per buffer
+    (200_000_000, -80_000_000, 80_000_000, 100, 0.02, 3, 200_000, 4),        # length 40 000, three steps per point
+    (10_000_000, -4_000_000, 4_000_000, 50, 0.05, 2, 30_000, 5),             # ppt 20 000, 1.5 points per buffer
+    (20_000_000, -8_000_000, 8_000_000, 100, 1.0, 1, 200_000, 4),            # ppt 200 000 = the buffer: one point per call, 782 stretches
 ]
 
 
