@@ -965,7 +965,7 @@ __device__ __forceinline__ void pfb_cu_filter_direct(const PfbCuArgs &a, float2 
         const int k = k0 + NT * c;
         const bool live = k < n && grp < a.dir_s && gw > 0;  // (columns beyond the frame, groups without a frame: no loads)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) w[c][j] = live ? a.window[(unsigned)(j * n + k)] : 0.f;
+        for (int j = 0; j < 4; ++j) w[c][j] = live && j < a.F ? a.window[(unsigned)(j * n + k)] : 0.f;
         ch[c] = mk2(1.f, 0.f);
         if (a.chirp && live) {
             const float2 cc = a.chirp[k];
@@ -975,7 +975,7 @@ __device__ __forceinline__ void pfb_cu_filter_direct(const PfbCuArgs &a, float2 
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             xr[c][b] = mk2(0.f, 0.f);
-            if (live && b < gw + 3) {
+            if (live && b < gw + a.F - 1) {      // (up to four taps: with fewer the last taps are zero and their blocks stay unloaded, zero)
                 const int q = q0 + b * n;
                 xr[c][b] = q < a.new_0 ? a.carry[q] : a.in[q - a.new_0];
             }
@@ -992,8 +992,10 @@ __device__ __forceinline__ void pfb_cu_filter_direct(const PfbCuArgs &a, float2 
                     if (fr < gw) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            acc.x += xr[c][fr + i].x * w[c][i];
-                            acc.y += xr[c][fr + i].y * w[c][i];
+                            if (i < a.F) {                 // (a later frame's block never enters this one: 0 * Inf)
+                                acc.x += xr[c][fr + i].x * w[c][i];
+                                acc.y += xr[c][fr + i].y * w[c][i];
+                            }
                         }
                         if (a.chirp) acc = cmul(acc, ch[c]);
                     }
@@ -1563,14 +1565,14 @@ int pfb_lds_plan(int n, int *radices) {
     return cnt <= 16 ? cnt : -1;
 }
 
-// Four taps and frames of 128 points and more: the run kernel filters straight out of global memory (one load per
+// Up to four taps and frames of 128 points and more: the run kernel filters straight out of global memory (one load per
 // block and column instead of four, no trip through the LDS) and is the faster one for powers of two as well --
 // same box, per 1 M-sample buffer: 256 points 10.1 against 10.3 us, 512: 10.2 / 10.8, 1024: 10.7 / 12.2, 2048:
 // 10.4 / 11.9; 16 points 9.9 against 9.4 and 64 points equal: short frames stay a frame set per workgroup
 // (profiles/r03_pfb_ab_direct.log).  GSDR_PFB_DIRECT=0 switches the direct filter off, and this rule with it.
 static bool pfb_cu_direct_pays(int nfft, int avg) {
     const int direct_env = env_direct.get();
-    return direct_env && avg == 4 && nfft >= 128;
+    return direct_env && avg >= 1 && avg <= 4 && nfft >= 128;
 }
 
 // Shape of the run-per-compute-unit kernel for frames of nfft points transformed at length `len` (nfft, or
@@ -1666,8 +1668,8 @@ static hipError_t launch_pfb_cu(const float2 *carry, int new_0, const float2 *in
         const int cpt = (nfft + threads - 1) / threads;
         dir_s = cpt == 1 ? threads / nfft : 1;             // groups of threads (frames shorter than the workgroup)
         dir_gs = (G + dir_s - 1) / dir_s;                  // frames per group
-        const int nb = dir_gs + 3;
-        if (avg != 4 || !direct_env) return 0;
+        const int nb = dir_gs + 3;                         // (the register shapes are those of four taps)
+        if (avg < 1 || avg > 4 || !direct_env) return 0;
         if (cpt == 1 && nb <= 11) return dir_s > 1 ? 4 : 1;
         if (cpt <= 2 && nb <= 7) return 2;
         if (cpt <= 3 && nb <= 5) return 5;
@@ -1681,7 +1683,7 @@ static hipError_t launch_pfb_cu(const float2 *carry, int new_0, const float2 *in
     // 1000: 12.4 / 12.9; from 1024 points on the full workgroup wins (1024: 10.9 against 11.2, 2048: 10.5 / 11.9,
     // and the matrix-core stage wants its sixteen waves: 1230: 13.5 / 17.0), profiles/r03_pfb_ab_nt.log
     const bool half_pays = nt_env == 512 || (nt_env == 0 && nfft < 1024 && !(a.n_radices > 0 && a.radices[0] > 13));
-    if (half_pays && avg == 4 && direct_env) {
+    if (half_pays && avg >= 1 && avg <= 4 && direct_env) {
         const int want2 = frames_n > 0 ? (frames_n + 2 * cus - 1) / (2 * cus) : 1;
         int G2 = 0, bo = 0, bl = 0, twl2 = 0, ds = 1, dg = 1;
         size_t lds2 = 0;

@@ -875,8 +875,8 @@ def pfb_lds_fits(nfft, avg=4):
         return False
     if (even(mm) + even(max(mm, avg * nfft)) + 128 + (nfft + 1) // 2) * 8 <= 156 * 1024:
         return True
-    # four taps, 128 points and more: the filter runs straight out of global memory and the second buffer holds no raw samples
-    return avg == 4 and 128 <= nfft <= 4096 and (2 * even(mm) + 128 + (nfft + 1) // 2) * 8 <= 156 * 1024
+    # up to four taps, 128 points and more: the filter runs straight out of global memory and the second buffer holds no raw samples
+    return avg <= 4 and 128 <= nfft <= 4096 and (2 * even(mm) + 128 + (nfft + 1) // 2) * 8 <= 156 * 1024
 
 
 @pytest.mark.parametrize("path", ["lds", "global"])
@@ -940,6 +940,10 @@ PFB_VARIANT_SHAPES = [
     (2600, 4, 80_000, 2),     # three columns per thread
     (4096, 4, 100_000, 2),    # four columns, a frame per unit
     (1018, 4, 40_000, 2),     # 2 * 509: Bluestein through 2048 (the run kernel under every switch but GSDR_PFB_CU=0)
+    (1024, 1, 30_000, 3),     # one tap: the direct filter with three zero taps
+    (1230, 2, 60_000, 3),     # two taps
+    (200, 3, 30_011, 3),      # three taps, thread groups
+    (1000, 6, 60_000, 3),     # six taps: staged through the LDS, point-wise
 ]
 
 
